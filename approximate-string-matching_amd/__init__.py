@@ -1,0 +1,390 @@
+"""MI355X-native batched pair aligner — Python host side over the C ABI (include/asm_mi355x.h).
+
+This package is plumbing: it binds libasm_mi355x.so (HIP kernels + C ABI, built in-tree by
+`make -C approximate-string-matching_amd lib`) with ctypes and mirrors the reference's per-pair interface
+for the ONE path this repo accelerates — `benchmark::_run_benchmark`
+(/root/reference/GASMA/benchmark/benchmark_utils.h:231-259: NW, LEAP, Greedy per read pair) — as whole-batch
+calls.  There is no CPU fallback: every compute call needs the library and a HIP device and raises otherwise.
+
+Import name: the directory is `approximate-string-matching_amd`; `import approximate_string_matching_amd`
+works through the loader module of that name at the repo root.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from dataclasses import dataclass
+from typing import Iterable, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libasm_mi355x.so")
+HEADER_PATH = os.path.join(_HERE, "..", "include", "asm_mi355x.h")
+
+NW, LEAP, GREEDY = 0, 1, 2
+ALIGNER_NAMES = {NW: "nw", LEAP: "leap", GREEDY: "greedy"}
+GREEDY_SEQUENTIAL, GREEDY_CLEAN = 0, 1
+GEN_EXACT_ERRORS, GEN_PER_BASE = 0, 1
+GREEDY_MAX_LENGTH = 128
+LEAP_MAX_LENGTH = 256
+MAX_LENGTH = 512
+
+
+class AsmError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"asm_mi355x error {code}: {message}")
+        self.code = code
+
+
+class Params(ctypes.Structure):
+    """asm_params: constructor arguments of `benchmark` (benchmark_utils.h:263-289) and of hurdle_matrix
+    (hurdle_matrix.h:552-559)."""
+
+    _fields_ = [("k", ctypes.c_int32), ("x", ctypes.c_int32), ("o", ctypes.c_int32), ("e", ctypes.c_int32),
+                ("p_match", ctypes.c_double), ("p_mismatch", ctypes.c_double), ("p_indel", ctypes.c_double)]
+
+    @classmethod
+    def default(cls, k: int = 3, x: int = 1, o: int = 1, e: int = 1, p_match: float = 0.80,
+                p_mismatch: float = 0.20 / 3, p_indel: float = 0.40 / 3) -> "Params":
+        return cls(k, x, o, e, p_match, p_mismatch, p_indel)
+
+
+class GenConfig(ctypes.Structure):
+    """asm_gen_config: seeded restatement of `Dataset` (benchmark_dataset.h:61-253)."""
+
+    _fields_ = [("seed", ctypes.c_uint64), ("kind", ctypes.c_int32), ("len_lo", ctypes.c_int32),
+                ("len_hi", ctypes.c_int32), ("err", ctypes.c_float), ("mismatch_rate", ctypes.c_float),
+                ("p_sub", ctypes.c_float), ("p_ins", ctypes.c_float), ("p_del", ctypes.c_float)]
+
+    @classmethod
+    def exact(cls, seed: int, length: int, err: float, mismatch_rate: float = 0.96, length_hi: Optional[int] = None):
+        """Dataset(num_reads, length, err, 0.96, exact=true) — benchmark.cpp:19."""
+        return cls(seed, GEN_EXACT_ERRORS, length, length_hi if length_hi is not None else length, err,
+                   mismatch_rate, 0.0, 0.0, 0.0)
+
+    @classmethod
+    def per_base(cls, seed: int, length: int, p_sub: float, p_ins: float, p_del: float,
+                 length_hi: Optional[int] = None):
+        """Independent per-base events; SRR611076-shaped rates are README.md:73-76 of the reference."""
+        return cls(seed, GEN_PER_BASE, length, length_hi if length_hi is not None else length, 0.0, 0.0, p_sub,
+                   p_ins, p_del)
+
+
+# The named workloads of BASELINE.json `configs`.
+def workload(name: str) -> Tuple[GenConfig, int, Params]:
+    """-> (generator config, number of pairs, aligner params) for C1..C5."""
+    if name == "C1":
+        return GenConfig.exact(1, 100, 0.05), 10_000, Params.default(k=3)
+    if name == "C2":
+        return GenConfig.exact(2, 100, 0.10), 1_000_000, Params.default(k=3)
+    if name == "C3":
+        return GenConfig.exact(3, 150, 0.20), 10_000_000, Params.default(k=30)
+    if name == "C4":
+        return GenConfig.per_base(4, 100, 0.02452, 0.000468, 0.000553), 10_000_000, Params.default(k=3)
+    if name == "C5":
+        return GenConfig.exact(5, 64, 0.10, length_hi=300), 10_000_000, Params.default(k=3)
+    raise KeyError(name)
+
+
+_lib = None
+
+
+def load_library() -> ctypes.CDLL:
+    """Loads the in-tree C-ABI library.  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AsmError(-2, f"{LIB_PATH} is missing — build it with `make -C {_HERE} lib` "
+                           "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    c = ctypes
+    vp, i32, i64, u64p = c.c_void_p, c.c_int, c.c_int64, c.POINTER(c.c_ulonglong)
+    sigs = {
+        "asm_version": (c.c_char_p, []),
+        "asm_default_params": (None, [c.POINTER(Params)]),
+        "asm_device_count": (i32, []),
+        "asm_create": (i32, [c.POINTER(vp), i32]),
+        "asm_destroy": (i32, [vp]),
+        "asm_last_error": (c.c_char_p, [vp]),
+        "asm_set_stream": (i32, [vp, vp]),
+        "asm_synchronize": (i32, [vp]),
+        "asm_generate_pairs": (i32, [c.POINTER(GenConfig), i64, i64, vp, vp, vp, c.c_size_t, vp, c.c_size_t]),
+        "asm_batch_upload": (i32, [vp, i64, vp, vp, vp, vp, i32, c.POINTER(vp)]),
+        "asm_batch_generate": (i32, [vp, c.POINTER(GenConfig), i64, i64, i32, c.POINTER(vp)]),
+        "asm_batch_free": (i32, [vp, vp]),
+        "asm_batch_size": (i64, [vp]),
+        "asm_batch_max_length": (i32, [vp]),
+        "asm_batch_download": (i32, [vp, vp, vp, vp, vp, c.c_size_t, vp, c.c_size_t]),
+        "asm_batch_pack_async": (i32, [vp, vp]),
+        "asm_align_batch_async": (i32, [vp, vp, i32, c.POINTER(Params), vp]),
+        "asm_align_batch": (i32, [vp, i32, i64, vp, vp, vp, vp, c.POINTER(Params), i32, vp]),
+        "asm_count_equal_async": (i32, [vp, vp, vp, i64, vp]),
+        "asm_device_malloc": (i32, [vp, c.c_size_t, c.POINTER(vp)]),
+        "asm_device_free": (i32, [vp, vp]),
+        "asm_memcpy_d2h": (i32, [vp, vp, vp, c.c_size_t]),
+        "asm_memcpy_h2d": (i32, [vp, vp, vp, c.c_size_t]),
+        "asm_memset_async": (i32, [vp, vp, i32, c.c_size_t]),
+        "asm_timer_create": (i32, [vp, c.POINTER(vp)]),
+        "asm_timer_start": (i32, [vp, vp]),
+        "asm_timer_stop": (i32, [vp, vp]),
+        "asm_timer_elapsed_ms": (i32, [vp, vp, c.POINTER(c.c_float)]),
+        "asm_timer_destroy": (i32, [vp, vp]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)  # AttributeError here = the library does not export what the header declares
+        fn.restype = res
+        fn.argtypes = args
+    lib._asm_symbols = tuple(sigs)
+    _lib = lib
+    return lib
+
+
+def device_count() -> int:
+    return int(load_library().asm_device_count())
+
+
+@dataclass
+class HostBatch:
+    """A batch of read pairs in the C ABI's layout: concatenated ASCII + n+1 prefix offsets."""
+
+    reads: np.ndarray     # uint8
+    read_off: np.ndarray  # uint32, n+1
+    refs: np.ndarray      # uint8
+    ref_off: np.ndarray   # uint32, n+1
+
+    @property
+    def n(self) -> int:
+        return int(self.read_off.shape[0] - 1)
+
+    @classmethod
+    def from_strings(cls, pairs: Iterable[Tuple[str, str]]) -> "HostBatch":
+        pairs = list(pairs)
+        ro = np.zeros(len(pairs) + 1, np.uint32)
+        fo = np.zeros(len(pairs) + 1, np.uint32)
+        if pairs:
+            ro[1:] = np.cumsum([len(p[0]) for p in pairs])
+            fo[1:] = np.cumsum([len(p[1]) for p in pairs])
+        reads = np.frombuffer("".join(p[0] for p in pairs).encode("ascii"), np.uint8).copy()
+        refs = np.frombuffer("".join(p[1] for p in pairs).encode("ascii"), np.uint8).copy()
+        return cls(reads, ro, refs, fo)
+
+    def pair(self, i: int) -> Tuple[str, str]:
+        a = self.reads[self.read_off[i]:self.read_off[i + 1]].tobytes().decode("ascii")
+        b = self.refs[self.ref_off[i]:self.ref_off[i + 1]].tobytes().decode("ascii")
+        return a, b
+
+    def slice(self, lo: int, hi: int) -> "HostBatch":
+        ro = self.read_off[lo:hi + 1].astype(np.int64)
+        fo = self.ref_off[lo:hi + 1].astype(np.int64)
+        return HostBatch(self.reads[ro[0]:ro[-1]].copy(), (ro - ro[0]).astype(np.uint32),
+                         self.refs[fo[0]:fo[-1]].copy(), (fo - fo[0]).astype(np.uint32))
+
+    def lengths(self) -> Tuple[np.ndarray, np.ndarray]:
+        return np.diff(self.read_off.astype(np.int64)), np.diff(self.ref_off.astype(np.int64))
+
+    @classmethod
+    def read_seq_file(cls, path: str, max_pairs: Optional[int] = None) -> "HostBatch":
+        """The harness's input format (benchmark_utils.h:325-352): line 2i = '>'+read, 2i+1 = '<'+ref; the
+        first character of every line is skipped blindly."""
+        pairs = []
+        with open(path, "r") as fh:
+            while max_pairs is None or len(pairs) < max_pairs:
+                a = fh.readline()
+                if not a:
+                    break
+                b = fh.readline()
+                pairs.append((a.rstrip("\n")[1:], b.rstrip("\n")[1:]))
+        return cls.from_strings(pairs)
+
+    def write_seq_file(self, path: str) -> None:
+        """benchmark_dataset.h:229,234 — '>%s\\n<%s\\n'."""
+        with open(path, "w") as fh:
+            for i in range(self.n):
+                a, b = self.pair(i)
+                fh.write(f">{a}\n<{b}\n")
+
+
+def generate_pairs(cfg: GenConfig, first: int, n: int) -> HostBatch:
+    """Host generator (asm_generate_pairs): pairs [first, first+n) of the seeded stream.  Needs no GPU."""
+    lib = load_library()
+    ro = np.zeros(n + 1, np.uint32)
+    fo = np.zeros(n + 1, np.uint32)
+    rc = lib.asm_generate_pairs(ctypes.byref(cfg), first, n, ro.ctypes.data, fo.ctypes.data, None, 0, None, 0)
+    if rc:
+        raise AsmError(rc, lib.asm_last_error(None).decode())
+    reads = np.zeros(max(int(ro[-1]), 1), np.uint8)
+    refs = np.zeros(max(int(fo[-1]), 1), np.uint8)
+    rc = lib.asm_generate_pairs(ctypes.byref(cfg), first, n, ro.ctypes.data, fo.ctypes.data, reads.ctypes.data,
+                                reads.size, refs.ctypes.data, refs.size)
+    if rc:
+        raise AsmError(rc, lib.asm_last_error(None).decode())
+    return HostBatch(reads[:int(ro[-1])], ro, refs[:int(fo[-1])], fo)
+
+
+class DeviceBatch:
+    """asm_batch: a device-resident batch (ASCII + packed bit planes)."""
+
+    def __init__(self, engine: "Engine", ptr: int):
+        self.engine, self.ptr = engine, ptr
+        self.n = int(engine.lib.asm_batch_size(ptr))
+        self.max_length = int(engine.lib.asm_batch_max_length(ptr))
+
+    def free(self) -> None:
+        if self.ptr:
+            self.engine.lib.asm_batch_free(self.engine.h, self.ptr)
+            self.ptr = None
+
+    def download(self) -> HostBatch:
+        lib, h = self.engine.lib, self.engine.h
+        ro = np.zeros(self.n + 1, np.uint32)
+        fo = np.zeros(self.n + 1, np.uint32)
+        self.engine._chk(lib.asm_batch_download(h, self.ptr, ro.ctypes.data, fo.ctypes.data, None, 0, None, 0))
+        reads = np.zeros(max(int(ro[-1]), 1), np.uint8)
+        refs = np.zeros(max(int(fo[-1]), 1), np.uint8)
+        self.engine._chk(lib.asm_batch_download(h, self.ptr, None, None, reads.ctypes.data, reads.size,
+                                                refs.ctypes.data, refs.size))
+        return HostBatch(reads[:int(ro[-1])], ro, refs[:int(fo[-1])], fo)
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Engine:
+    """asm_handle: one per GPU.  All device work of the hot path goes through here."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        rc = self.lib.asm_create(ctypes.byref(h), device)
+        if rc:
+            raise AsmError(rc, self.lib.asm_last_error(None).decode())
+        self.h = h
+        self.device = device
+
+    def _chk(self, rc: int) -> None:
+        if rc:
+            raise AsmError(rc, self.lib.asm_last_error(self.h).decode())
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.lib.asm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream: Optional[int]) -> None:
+        self._chk(self.lib.asm_set_stream(self.h, hip_stream))
+
+    def synchronize(self) -> None:
+        self._chk(self.lib.asm_synchronize(self.h))
+
+    # ---- batches ----
+    def upload(self, hb: HostBatch, greedy_mode: int = GREEDY_CLEAN) -> DeviceBatch:
+        ptr = ctypes.c_void_p()
+        reads = np.ascontiguousarray(hb.reads, np.uint8)
+        refs = np.ascontiguousarray(hb.refs, np.uint8)
+        ro = np.ascontiguousarray(hb.read_off, np.uint32)
+        fo = np.ascontiguousarray(hb.ref_off, np.uint32)
+        self._chk(self.lib.asm_batch_upload(self.h, hb.n, reads.ctypes.data, ro.ctypes.data, refs.ctypes.data,
+                                            fo.ctypes.data, greedy_mode, ctypes.byref(ptr)))
+        return DeviceBatch(self, ptr)
+
+    def generate(self, cfg: GenConfig, first: int, n: int, greedy_mode: int = GREEDY_CLEAN) -> DeviceBatch:
+        ptr = ctypes.c_void_p()
+        self._chk(self.lib.asm_batch_generate(self.h, ctypes.byref(cfg), first, n, greedy_mode, ctypes.byref(ptr)))
+        return DeviceBatch(self, ptr)
+
+    def pack_async(self, batch: DeviceBatch) -> None:
+        self._chk(self.lib.asm_batch_pack_async(self.h, batch.ptr))
+
+    # ---- device memory ----
+    def malloc(self, nbytes: int) -> int:
+        p = ctypes.c_void_p()
+        self._chk(self.lib.asm_device_malloc(self.h, nbytes, ctypes.byref(p)))
+        return p.value
+
+    def free(self, ptr: int) -> None:
+        self._chk(self.lib.asm_device_free(self.h, ptr))
+
+    def to_host(self, ptr: int, count: int, dtype=np.int32) -> np.ndarray:
+        out = np.zeros(count, dtype)
+        self._chk(self.lib.asm_memcpy_d2h(self.h, out.ctypes.data, ptr, out.nbytes))
+        return out
+
+    def memset_async(self, ptr: int, value: int, nbytes: int) -> None:
+        self._chk(self.lib.asm_memset_async(self.h, ptr, value, nbytes))
+
+    # ---- the hot path ----
+    def align_async(self, batch: DeviceBatch, aligner: int, params: Params, d_out: int) -> None:
+        """One aligner over a resident batch into a device int32[n] buffer (enqueue only)."""
+        self._chk(self.lib.asm_align_batch_async(self.h, batch.ptr, aligner, ctypes.byref(params), d_out))
+
+    def align(self, batch: DeviceBatch, aligner: int, params: Params) -> np.ndarray:
+        d_out = self.malloc(4 * max(batch.n, 1))
+        try:
+            self.align_async(batch, aligner, params, d_out)
+            return self.to_host(d_out, batch.n)
+        finally:
+            self.free(d_out)
+
+    def align_host(self, hb: HostBatch, aligner: int, params: Params, greedy_mode: int = GREEDY_CLEAN) -> np.ndarray:
+        """asm_align_batch: host in, host out — `align(read, ref, k)` for every pair of the batch."""
+        out = np.zeros(hb.n, np.int32)
+        reads = np.ascontiguousarray(hb.reads, np.uint8)
+        refs = np.ascontiguousarray(hb.refs, np.uint8)
+        ro = np.ascontiguousarray(hb.read_off, np.uint32)
+        fo = np.ascontiguousarray(hb.ref_off, np.uint32)
+        self._chk(self.lib.asm_align_batch(self.h, aligner, hb.n, reads.ctypes.data, ro.ctypes.data, refs.ctypes.data,
+                                           fo.ctypes.data, ctypes.byref(params), greedy_mode, out.ctypes.data))
+        return out
+
+    def count_equal_async(self, d_a: int, d_b: int, n: int, d_count: int) -> None:
+        self._chk(self.lib.asm_count_equal_async(self.h, d_a, d_b, n, d_count))
+
+    # ---- timing ----
+    def timer(self) -> "Timer":
+        return Timer(self)
+
+
+class Timer:
+    """HIP events on the engine's stream."""
+
+    def __init__(self, engine: Engine):
+        self.e = engine
+        self.t = ctypes.c_void_p()
+        engine._chk(engine.lib.asm_timer_create(engine.h, ctypes.byref(self.t)))
+
+    def start(self) -> None:
+        self.e._chk(self.e.lib.asm_timer_start(self.e.h, self.t))
+
+    def stop(self) -> None:
+        self.e._chk(self.e.lib.asm_timer_stop(self.e.h, self.t))
+
+    def elapsed_ms(self) -> float:
+        ms = ctypes.c_float()
+        self.e._chk(self.e.lib.asm_timer_elapsed_ms(self.e.h, self.t, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            self.e.lib.asm_timer_destroy(self.e.h, self.t)
+        except Exception:
+            pass
+
+
+def declared_symbols() -> Sequence[str]:
+    """Function names declared in include/asm_mi355x.h (parsed from the header text)."""
+    import re
+
+    with open(HEADER_PATH) as fh:
+        text = fh.read()
+    return sorted(set(re.findall(r"\b(asm_[a-z0-9_]+)\s*\(", text)) - {"asm_handle", "asm_batch"})

@@ -1,0 +1,109 @@
+// 128-bit bit-vector primitives for the device kernels (gfx950).
+//
+// Device counterpart of the reference's int_128bit (GASMA/utils.h:49-271): same value semantics, including
+// the corner cases the Greedy aligner relies on (shift counts outside [0,127] give 0, first_one of an empty
+// vector is 128, pop_count_between of an empty or inverted range is 0).  Written for the CDNA4 scalar/vector
+// integer pipes: a vector is two 64-bit halves held in VGPRs; `v_lshrrev_b64`/`v_lshlrev_b64`, `v_ffbl_b32`
+// and `v_bcnt_u32_b32` do the work, selects replace branches so a wave never diverges inside a primitive.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ASM_DEV __device__ __forceinline__
+
+typedef unsigned long long u64;
+
+struct V128 {
+    u64 lo, hi;
+};
+
+ASM_DEV V128 v_make(u64 lo, u64 hi) {
+    V128 r;
+    r.lo = lo;
+    r.hi = hi;
+    return r;
+}
+ASM_DEV V128 v_from_uint4(uint4 q) { return v_make((u64)q.x | ((u64)q.y << 32), (u64)q.z | ((u64)q.w << 32)); }
+ASM_DEV V128 v_and(V128 a, V128 b) { return v_make(a.lo & b.lo, a.hi & b.hi); }
+ASM_DEV V128 v_or(V128 a, V128 b) { return v_make(a.lo | b.lo, a.hi | b.hi); }
+ASM_DEV V128 v_xor(V128 a, V128 b) { return v_make(a.lo ^ b.lo, a.hi ^ b.hi); }
+ASM_DEV V128 v_not(V128 a) { return v_make(~a.lo, ~a.hi); }
+
+// utils.h:143-153 "shift_left": bits move toward index 0; 0 for s outside [0,127].
+ASM_DEV V128 v_toward0(V128 v, int s) {
+    const bool dead = (unsigned)s >= 128u;
+    const bool big = s >= 64;
+    const int r = s & 63;
+    const u64 a = big ? v.hi : v.lo;
+    const u64 b = big ? 0ull : v.hi;
+    u64 lo = (a >> r) | (r ? (b << (64 - r)) : 0ull);
+    u64 hi = b >> r;
+    return v_make(dead ? 0ull : lo, dead ? 0ull : hi);
+}
+
+// utils.h:131-141 "shift_right": bits move away from index 0; 0 for s outside [0,127].
+ASM_DEV V128 v_away0(V128 v, int s) {
+    const bool dead = (unsigned)s >= 128u;
+    const bool big = s >= 64;
+    const int r = s & 63;
+    const u64 a = big ? v.lo : v.hi;
+    const u64 b = big ? 0ull : v.lo;
+    u64 hi = (a << r) | (r ? (b >> (64 - r)) : 0ull);
+    u64 lo = b << r;
+    return v_make(dead ? 0ull : lo, dead ? 0ull : hi);
+}
+
+// utils.h:168-182: index of the lowest set bit, 128 when there is none.
+ASM_DEV int v_first_one(V128 v) {
+    int a = v.lo ? __builtin_ctzll(v.lo) : 64;
+    int b = v.hi ? __builtin_ctzll(v.hi) : 64;
+    return v.lo ? a : 64 + b;
+}
+// utils.h:187-191
+ASM_DEV int v_first_zero(V128 v) { return v_first_one(v_not(v)); }
+
+ASM_DEV int v_popcount(V128 v) { return __popcll(v.lo) + __popcll(v.hi); }
+
+// utils.h:263-270: ones in [from,to); 0 when from+128-to falls outside [0,127] or from outside [0,127].
+ASM_DEV int v_pop_between(V128 v, int from, int to) {
+    return v_popcount(v_away0(v_toward0(v, from), from + 128 - to));
+}
+
+// utils.h:200-216 with threshold 1: a set bit survives only next to another set bit.
+ASM_DEV V128 v_flip_short_hurdles1(V128 v) {
+    V128 a = v_toward0(v, 1), b = v_away0(v, 1);
+    return v_and(v, v_or(a, b));
+}
+
+// utils.h:576-579
+ASM_DEV int lane_penalty(int a, int b, int o, int e) {
+    int d = a - b;
+    d = d < 0 ? -d : d;
+    return d == 0 ? 0 : o + e * (d - 1);
+}
+
+// utils.h:587-593
+ASM_DEV int fwd_col(int l1, int l2) {
+    int a1 = l1 < 0 ? -l1 : l1, a2 = l2 < 0 ? -l2 : l2;
+    int same = a1 > a2 ? a1 - a2 : 0;
+    return (l1 * l2 >= 0) ? same : a1;
+}
+
+// hurdle_matrix.h:58-68
+ASM_DEV int lane_destination(int m, int n, int lane) {
+    int r;
+    if (m >= n) {
+        r = lane > 0 ? n - lane : (lane >= n - m ? n : m + lane);
+    } else {
+        r = lane < 0 ? m + lane : (lane <= n - m ? m : n - lane);
+    }
+    return r;
+}
+
+// mask with bits [0,len) set, len in [0,128]
+ASM_DEV V128 v_low_ones(int len) {
+    u64 lo = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
+    int h = len - 64;
+    u64 hi = h <= 0 ? 0ull : (h >= 64 ? ~0ull : ((1ull << h) - 1ull));
+    return v_make(lo, hi);
+}

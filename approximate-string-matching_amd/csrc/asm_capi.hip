@@ -1,0 +1,583 @@
+// C ABI of libasm_mi355x.so (declared in include/asm_mi355x.h): handle/stream management, device-resident
+// batches, kernel dispatch.  Host side is C++17 compiled by hipcc; nothing here computes alignments on the
+// CPU — without a HIP device every compute entry point returns ASM_ENODEVICE.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/asm_mi355x.h"
+#include "asm_kernels.h"
+#include "asm_wide.h"
+#include "asm_tails.h"
+
+struct asm_handle {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+};
+
+struct asm_batch {
+    int64_t n = 0;
+    int w4 = 1;
+    int maxlen = 0;
+    int greedy_mode = ASM_GREEDY_CLEAN;
+    size_t reads_bytes = 0, refs_bytes = 0;
+    char* d_reads = nullptr;
+    char* d_refs = nullptr;
+    uint32_t* d_read_off = nullptr;
+    uint32_t* d_ref_off = nullptr;
+    uint4* d_planes = nullptr;
+    uint32_t* d_lens = nullptr;
+    uint4* d_tails = nullptr;
+};
+
+static thread_local std::string g_err;
+
+static int fail(asm_handle* h, int code, const std::string& msg) {
+    g_err = msg;
+    if (h) h->err = msg;
+    return code;
+}
+
+#define HIPCHK(h, call)                                                                           \
+    do {                                                                                          \
+        hipError_t _e = (call);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            return fail(h, _e == hipErrorOutOfMemory ? ASM_ENOMEM : ASM_ENODEVICE,                \
+                        std::string(#call) + ": " + hipGetErrorString(_e));                       \
+        }                                                                                         \
+    } while (0)
+
+static int grid_for(int64_t n) { return (int)((n + ASM_BLOCK - 1) / ASM_BLOCK); }
+
+template <int K>
+static void launch_greedy(asm_handle* h, const asm_batch* b, const GreedyArgs& ga, int32_t* d_out) {
+    hipLaunchKernelGGL(greedy_kernel<K>, dim3(grid_for(b->n)), dim3(ASM_BLOCK), 0, h->stream, b->d_planes, b->d_lens,
+                       (long)b->n, b->w4, ga, d_out);
+}
+
+template <int K>
+static void launch_leap_unit(asm_handle* h, const asm_batch* b, int32_t* d_out) {
+    if (b->maxlen <= 128)
+        hipLaunchKernelGGL((leap_unit_kernel<K, 2>), dim3(grid_for(b->n)), dim3(ASM_BLOCK), 0, h->stream, b->d_planes,
+                           b->d_lens, (long)b->n, b->w4, d_out);
+    else
+        hipLaunchKernelGGL((leap_unit_kernel<K, 4>), dim3(grid_for(b->n)), dim3(ASM_BLOCK), 0, h->stream, b->d_planes,
+                           b->d_lens, (long)b->n, b->w4, d_out);
+}
+
+extern "C" {
+
+const char* asm_version(void) { return "asm_mi355x 0.1 (gfx950)"; }
+
+void asm_default_params(asm_params* p) {
+    if (!p) return;
+    p->k = 3; /* benchmark.cpp:22 */
+    p->x = p->o = p->e = 1;
+    p->p_match = 0.80; /* hurdle_matrix.h:557-559 */
+    p->p_mismatch = 0.20 / 3;
+    p->p_indel = 0.40 / 3;
+}
+
+int asm_device_count(void) {
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
+
+int asm_create(asm_handle** out, int device) {
+    if (!out) return fail(nullptr, ASM_EINVAL, "asm_create: out is NULL");
+    *out = nullptr;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess || c <= 0)
+        return fail(nullptr, ASM_ENODEVICE, "asm_create: no HIP device is visible (this library has no CPU path)");
+    if (device < 0 || device >= c) return fail(nullptr, ASM_EINVAL, "asm_create: device index out of range");
+    asm_handle* h = new asm_handle;
+    h->device = device;
+    HIPCHK(h, hipSetDevice(device));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+    *out = h;
+    return ASM_OK;
+}
+
+int asm_destroy(asm_handle* h) {
+    if (!h) return ASM_OK;
+    (void)hipSetDevice(h->device);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return ASM_OK;
+}
+
+const char* asm_last_error(const asm_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+int asm_set_stream(asm_handle* h, void* hip_stream) {
+    if (!h) return fail(nullptr, ASM_EINVAL, "asm_set_stream: NULL handle");
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return ASM_OK;
+}
+
+int asm_synchronize(asm_handle* h) {
+    if (!h) return fail(nullptr, ASM_EINVAL, "asm_synchronize: NULL handle");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ASM_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------------- */
+static int check_gen(const asm_gen_config* cfg) {
+    if (!cfg) return fail(nullptr, ASM_EINVAL, "generator: cfg is NULL");
+    if (cfg->len_lo < 1 || cfg->len_hi < cfg->len_lo || cfg->len_hi > ASM_MAX_LENGTH)
+        return fail(nullptr, ASM_EINVAL, "generator: need 1 <= len_lo <= len_hi <= ASM_MAX_LENGTH");
+    if (cfg->kind == ASM_GEN_EXACT_ERRORS) {
+        /* benchmark_dataset.h:192-204 */
+        if (!(cfg->err >= 0.f && cfg->err <= 0.7f)) return fail(nullptr, ASM_EINVAL, "generator: err must be in [0, 0.7]");
+        if (!(cfg->mismatch_rate >= 0.f && cfg->mismatch_rate <= 1.f))
+            return fail(nullptr, ASM_EINVAL, "generator: mismatch_rate must be in [0, 1]");
+    } else if (cfg->kind == ASM_GEN_PER_BASE) {
+        if (!(cfg->p_sub >= 0.f && cfg->p_ins >= 0.f && cfg->p_del >= 0.f && cfg->p_sub + cfg->p_del <= 1.f &&
+              cfg->p_ins <= 1.f))
+            return fail(nullptr, ASM_EINVAL, "generator: per-base rates out of range");
+    } else {
+        return fail(nullptr, ASM_EINVAL, "generator: unknown kind");
+    }
+    return ASM_OK;
+}
+
+int asm_generate_pairs(const asm_gen_config* cfg, int64_t first, int64_t n, uint32_t* read_off, uint32_t* ref_off,
+                       char* reads, size_t reads_cap, char* refs, size_t refs_cap) {
+    int rc = check_gen(cfg);
+    if (rc) return rc;
+    if (n < 0 || first < 0 || !read_off || !ref_off) return fail(nullptr, ASM_EINVAL, "asm_generate_pairs: bad arguments");
+    uint64_t ra = 0, rb = 0;
+    for (int64_t i = 0; i < n; i++) {
+        int m, nn;
+        asm_gen_lengths(cfg, (uint64_t)(first + i), &m, &nn);
+        read_off[i] = (uint32_t)ra;
+        ref_off[i] = (uint32_t)rb;
+        ra += (uint64_t)m;
+        rb += (uint64_t)nn;
+        if (ra > 0xffffffffull || rb > 0xffffffffull)
+            return fail(nullptr, ASM_EUNSUPPORTED, "asm_generate_pairs: batch exceeds 4 GiB of text; split it");
+    }
+    read_off[n] = (uint32_t)ra;
+    ref_off[n] = (uint32_t)rb;
+    if (!reads || !refs) return ASM_OK; /* sizing pass */
+    if (reads_cap < ra || refs_cap < rb) return fail(nullptr, ASM_EINVAL, "asm_generate_pairs: output buffers too small");
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        char rd[ASM_MAX_LENGTH + 8], tx[ASM_GEN_MAX_TEXT];
+        int m, nn;
+        asm_gen_pair(cfg, (uint64_t)(first + i), rd, tx, &m, &nn);
+        memcpy(reads + read_off[i], rd, (size_t)m);
+        memcpy(refs + ref_off[i], tx, (size_t)nn);
+    }
+    return ASM_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------------- */
+
+static void batch_release(asm_batch* b) {
+    if (!b) return;
+    (void)hipFree(b->d_reads);
+    (void)hipFree(b->d_refs);
+    (void)hipFree(b->d_read_off);
+    (void)hipFree(b->d_ref_off);
+    (void)hipFree(b->d_planes);
+    (void)hipFree(b->d_lens);
+    (void)hipFree(b->d_tails);
+    delete b;
+}
+
+static int batch_alloc_packed(asm_handle* h, asm_batch* b) {
+    HIPCHK(h, hipMalloc((void**)&b->d_planes, sizeof(uint4) * 4 * (size_t)b->w4 * (size_t)(b->n > 0 ? b->n : 1)));
+    HIPCHK(h, hipMalloc((void**)&b->d_lens, sizeof(uint32_t) * (size_t)(b->n > 0 ? b->n : 1)));
+    return ASM_OK;
+}
+
+int asm_batch_pack_async(asm_handle* h, asm_batch* b) {
+    if (!h || !b) return fail(h, ASM_EINVAL, "asm_batch_pack_async: NULL argument");
+    if (b->n == 0) return ASM_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    /* one wave per pair, grid capped: 256 CUs x 8 blocks, 4 waves per block */
+    int64_t waves = b->n;
+    int64_t blocks = (waves + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)blocks), dim3(ASM_BLOCK), 0, h->stream, b->d_reads, b->d_read_off,
+                       b->d_refs, b->d_ref_off, b->d_tails, b->d_planes, b->d_lens, (long)b->n, b->w4);
+    HIPCHK(h, hipGetLastError());
+    return ASM_OK;
+}
+
+int asm_batch_upload(asm_handle* h, int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
+                     const uint32_t* ref_off, int greedy_mode, asm_batch** out) {
+    if (!h || !out || n < 0 || !read_off || !ref_off || (n > 0 && (!reads || !refs)))
+        return fail(h, ASM_EINVAL, "asm_batch_upload: bad arguments");
+    if (greedy_mode != ASM_GREEDY_CLEAN && greedy_mode != ASM_GREEDY_SEQUENTIAL)
+        return fail(h, ASM_EINVAL, "asm_batch_upload: unknown greedy_mode");
+    *out = nullptr;
+    HIPCHK(h, hipSetDevice(h->device));
+    int maxlen = 0;
+    for (int64_t i = 0; i < n; i++) {
+        if (read_off[i + 1] < read_off[i] || ref_off[i + 1] < ref_off[i])
+            return fail(h, ASM_EINVAL, "asm_batch_upload: offsets must be non-decreasing");
+        int m = (int)(read_off[i + 1] - read_off[i]), nn = (int)(ref_off[i + 1] - ref_off[i]);
+        if (m > maxlen) maxlen = m;
+        if (nn > maxlen) maxlen = nn;
+    }
+    if (maxlen > ASM_MAX_LENGTH)
+        return fail(h, ASM_EUNSUPPORTED, "asm_batch_upload: a sequence is longer than ASM_MAX_LENGTH");
+    asm_batch* b = new asm_batch;
+    b->n = n;
+    b->maxlen = maxlen;
+    b->w4 = maxlen <= 128 ? 1 : (maxlen + 127) / 128;
+    b->greedy_mode = greedy_mode;
+    b->reads_bytes = n ? read_off[n] : 0;
+    b->refs_bytes = n ? ref_off[n] : 0;
+    int rc = ASM_OK;
+    do {
+#define TRY(call)                                          \
+    if ((call) != hipSuccess) {                            \
+        rc = fail(h, ASM_ENOMEM, std::string(#call) + " failed"); \
+        break;                                             \
+    }
+        TRY(hipMalloc((void**)&b->d_reads, b->reads_bytes + 16));
+        TRY(hipMalloc((void**)&b->d_refs, b->refs_bytes + 16));
+        TRY(hipMalloc((void**)&b->d_read_off, sizeof(uint32_t) * (size_t)(n + 1)));
+        TRY(hipMalloc((void**)&b->d_ref_off, sizeof(uint32_t) * (size_t)(n + 1)));
+        TRY(hipMemcpyAsync(b->d_reads, reads, b->reads_bytes, hipMemcpyHostToDevice, h->stream));
+        TRY(hipMemcpyAsync(b->d_refs, refs, b->refs_bytes, hipMemcpyHostToDevice, h->stream));
+        TRY(hipMemcpyAsync(b->d_read_off, read_off, sizeof(uint32_t) * (size_t)(n + 1), hipMemcpyHostToDevice, h->stream));
+        TRY(hipMemcpyAsync(b->d_ref_off, ref_off, sizeof(uint32_t) * (size_t)(n + 1), hipMemcpyHostToDevice, h->stream));
+        if (greedy_mode == ASM_GREEDY_SEQUENTIAL && n > 0) {
+            std::vector<uint32_t> tails((size_t)16 * (size_t)n);
+            asm_resolve_tails_host(n, reads, read_off, refs, ref_off, tails.data());
+            TRY(hipMalloc((void**)&b->d_tails, sizeof(uint4) * 4 * (size_t)n));
+            TRY(hipMemcpyAsync(b->d_tails, tails.data(), sizeof(uint4) * 4 * (size_t)n, hipMemcpyHostToDevice, h->stream));
+            TRY(hipStreamSynchronize(h->stream)); /* `tails` goes out of scope */
+        }
+#undef TRY
+        rc = batch_alloc_packed(h, b);
+        if (rc) break;
+        rc = asm_batch_pack_async(h, b);
+        if (rc) break;
+        if (hipStreamSynchronize(h->stream) != hipSuccess) {
+            rc = fail(h, ASM_ENODEVICE, "asm_batch_upload: stream synchronize failed");
+            break;
+        }
+    } while (0);
+    if (rc) {
+        batch_release(b);
+        return rc;
+    }
+    *out = b;
+    return ASM_OK;
+}
+
+int asm_batch_generate(asm_handle* h, const asm_gen_config* cfg, int64_t first, int64_t n, int greedy_mode,
+                       asm_batch** out) {
+    if (!h || !out || n < 0 || first < 0) return fail(h, ASM_EINVAL, "asm_batch_generate: bad arguments");
+    int rc = check_gen(cfg);
+    if (rc) return fail(h, rc, g_err);
+    if (greedy_mode != ASM_GREEDY_CLEAN)
+        return fail(h, ASM_EUNSUPPORTED,
+                    "asm_batch_generate: only ASM_GREEDY_CLEAN (sequential tails are resolved by asm_batch_upload)");
+    *out = nullptr;
+    HIPCHK(h, hipSetDevice(h->device));
+    asm_batch* b = new asm_batch;
+    b->n = n;
+    b->greedy_mode = greedy_mode;
+    uint32_t *d_m = nullptr, *d_n = nullptr, *d_max = nullptr;
+    void* d_tmp = nullptr;
+    rc = ASM_OK;
+    do {
+#define TRY(call)                                                  \
+    if ((call) != hipSuccess) {                                    \
+        rc = fail(h, ASM_ENODEVICE, std::string(#call) + " failed"); \
+        break;                                                     \
+    }
+        const size_t cnt = (size_t)n + 1;
+        TRY(hipMalloc((void**)&d_m, sizeof(uint32_t) * cnt));
+        TRY(hipMalloc((void**)&d_n, sizeof(uint32_t) * cnt));
+        TRY(hipMalloc((void**)&d_max, sizeof(uint32_t) * 2));
+        TRY(hipMalloc((void**)&b->d_read_off, sizeof(uint32_t) * cnt));
+        TRY(hipMalloc((void**)&b->d_ref_off, sizeof(uint32_t) * cnt));
+        TRY(hipMemsetAsync(d_m, 0, sizeof(uint32_t) * cnt, h->stream));
+        TRY(hipMemsetAsync(d_n, 0, sizeof(uint32_t) * cnt, h->stream));
+        if (n > 0) {
+            hipLaunchKernelGGL(gen_lengths_kernel, dim3(grid_for(n)), dim3(ASM_BLOCK), 0, h->stream, *cfg, (long)first,
+                               (long)n, d_m, d_n);
+            TRY(hipGetLastError());
+        }
+        size_t tmp_bytes = 0, t2 = 0;
+        TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_m, b->d_read_off, (int)cnt, h->stream));
+        TRY(hipcub::DeviceReduce::Max(nullptr, t2, d_n, d_max, (int)cnt, h->stream));
+        if (t2 > tmp_bytes) tmp_bytes = t2;
+        TRY(hipMalloc(&d_tmp, tmp_bytes + 16));
+        TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_m, b->d_read_off, (int)cnt, h->stream));
+        TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_n, b->d_ref_off, (int)cnt, h->stream));
+        TRY(hipcub::DeviceReduce::Max(d_tmp, tmp_bytes, d_m, d_max, (int)cnt, h->stream));
+        TRY(hipcub::DeviceReduce::Max(d_tmp, tmp_bytes, d_n, d_max + 1, (int)cnt, h->stream));
+        uint32_t tot[2] = {0, 0}, mx[2] = {0, 0};
+        TRY(hipMemcpyAsync(&tot[0], b->d_read_off + n, 4, hipMemcpyDeviceToHost, h->stream));
+        TRY(hipMemcpyAsync(&tot[1], b->d_ref_off + n, 4, hipMemcpyDeviceToHost, h->stream));
+        TRY(hipMemcpyAsync(mx, d_max, 8, hipMemcpyDeviceToHost, h->stream));
+        TRY(hipStreamSynchronize(h->stream));
+        /* 32-bit offsets: the host-side bound (n * worst length) must stay below 4 GiB */
+        {
+            double bound = (double)n * (double)(cfg->len_hi * 2 + 2);
+            if (bound >= 4294967295.0 && (double)n * (double)(mx[0] > mx[1] ? mx[0] : mx[1]) >= 4294967295.0) {
+                rc = fail(h, ASM_EUNSUPPORTED, "asm_batch_generate: batch exceeds 4 GiB of text; split it");
+                break;
+            }
+        }
+        b->reads_bytes = tot[0];
+        b->refs_bytes = tot[1];
+        b->maxlen = (int)(mx[0] > mx[1] ? mx[0] : mx[1]);
+        if (b->maxlen > ASM_MAX_LENGTH) {
+            rc = fail(h, ASM_EUNSUPPORTED, "asm_batch_generate: a generated sequence exceeds ASM_MAX_LENGTH");
+            break;
+        }
+        b->w4 = b->maxlen <= 128 ? 1 : (b->maxlen + 127) / 128;
+        TRY(hipMalloc((void**)&b->d_reads, b->reads_bytes + 16));
+        TRY(hipMalloc((void**)&b->d_refs, b->refs_bytes + 16));
+        if (n > 0) {
+            hipLaunchKernelGGL(gen_fill_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, *cfg, (long)first,
+                               (long)n, b->d_read_off, b->d_ref_off, b->d_reads, b->d_refs);
+            TRY(hipGetLastError());
+        }
+#undef TRY
+        rc = batch_alloc_packed(h, b);
+        if (rc) break;
+        rc = asm_batch_pack_async(h, b);
+        if (rc) break;
+        if (hipStreamSynchronize(h->stream) != hipSuccess) {
+            rc = fail(h, ASM_ENODEVICE, "asm_batch_generate: stream synchronize failed");
+            break;
+        }
+    } while (0);
+    (void)hipFree(d_m);
+    (void)hipFree(d_n);
+    (void)hipFree(d_max);
+    (void)hipFree(d_tmp);
+    if (rc) {
+        batch_release(b);
+        return rc;
+    }
+    *out = b;
+    return ASM_OK;
+}
+
+int asm_batch_free(asm_handle* h, asm_batch* b) {
+    if (h) (void)hipSetDevice(h->device);
+    batch_release(b);
+    return ASM_OK;
+}
+
+int64_t asm_batch_size(const asm_batch* b) { return b ? b->n : 0; }
+int asm_batch_max_length(const asm_batch* b) { return b ? b->maxlen : 0; }
+
+int asm_batch_download(asm_handle* h, const asm_batch* b, uint32_t* read_off, uint32_t* ref_off, char* reads,
+                       size_t reads_cap, char* refs, size_t refs_cap) {
+    if (!h || !b) return fail(h, ASM_EINVAL, "asm_batch_download: NULL argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (read_off) HIPCHK(h, hipMemcpy(read_off, b->d_read_off, sizeof(uint32_t) * (size_t)(b->n + 1), hipMemcpyDeviceToHost));
+    if (ref_off) HIPCHK(h, hipMemcpy(ref_off, b->d_ref_off, sizeof(uint32_t) * (size_t)(b->n + 1), hipMemcpyDeviceToHost));
+    if (reads) {
+        if (reads_cap < b->reads_bytes) return fail(h, ASM_EINVAL, "asm_batch_download: reads buffer too small");
+        HIPCHK(h, hipMemcpy(reads, b->d_reads, b->reads_bytes, hipMemcpyDeviceToHost));
+    }
+    if (refs) {
+        if (refs_cap < b->refs_bytes) return fail(h, ASM_EINVAL, "asm_batch_download: refs buffer too small");
+        HIPCHK(h, hipMemcpy(refs, b->d_refs, b->refs_bytes, hipMemcpyDeviceToHost));
+    }
+    return ASM_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------------- */
+static int check_params(asm_handle* h, int aligner, const asm_params* p) {
+    if (!p) return fail(h, ASM_EINVAL, "params is NULL");
+    if (p->x < 0 || p->o < 0 || p->e < 0) return fail(h, ASM_EINVAL, "penalties must be non-negative");
+    if (aligner == ASM_GREEDY) {
+        if (p->k < 0 || p->k > ASM_GREEDY_MAX_K) return fail(h, ASM_EINVAL, "Greedy: k must be in [0, 50] (MAX_K, hurdle_matrix.h:8)");
+        if (!(p->p_match > 0 && p->p_mismatch > 0 && p->p_indel > 0)) return fail(h, ASM_EINVAL, "Greedy: probabilities must be positive");
+    } else if (aligner == ASM_LEAP) {
+        if (p->k < 0 || p->k > ASM_WIDE_MAX_K) return fail(h, ASM_EINVAL, "LEAP: k out of range");
+        /* the recurrence reads generation e-o / e-ext / e-x: zero penalties would be same-generation reads,
+         * and LV_BAG.cpp:165 assumes open >= extend */
+        if (p->x < 1 || p->o < 1 || p->e < 1 || p->o < p->e)
+            return fail(h, ASM_EINVAL, "LEAP: need x >= 1, o >= e >= 1 (LV_BAG.cpp:165-166)");
+        if (p->x > ASM_WIDE_MAX_PENALTY || p->o > ASM_WIDE_MAX_PENALTY)
+            return fail(h, ASM_EUNSUPPORTED, "LEAP: penalties above the compiled history depth");
+    } else if (aligner != ASM_NW) {
+        return fail(h, ASM_EINVAL, "unknown aligner id");
+    }
+    return ASM_OK;
+}
+
+int asm_align_batch_async(asm_handle* h, const asm_batch* b, int aligner, const asm_params* p, int32_t* d_penalties) {
+    if (!h || !b || !d_penalties) return fail(h, ASM_EINVAL, "asm_align_batch_async: NULL argument");
+    int rc = check_params(h, aligner, p);
+    if (rc) return rc;
+    if (b->n == 0) return ASM_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    const bool unit = (p->x == 1 && p->o == 1 && p->e == 1);
+    if (aligner == ASM_GREEDY) {
+        GreedyArgs ga;
+        ga.x = p->x, ga.o = p->o, ga.e = p->e;
+        ga.sig_match = log(p->p_match / 0.25); /* hurdle_matrix.h:536-538 */
+        ga.sig_mismatch = log(p->p_mismatch / 0.25);
+        ga.sig_indel = log(p->p_indel / 2 / 0.25);
+        switch (p->k) {
+            case 1: launch_greedy<1>(h, b, ga, d_penalties); break;
+            case 2: launch_greedy<2>(h, b, ga, d_penalties); break;
+            case 3: launch_greedy<3>(h, b, ga, d_penalties); break;
+            case 4: launch_greedy<4>(h, b, ga, d_penalties); break;
+            case 5: launch_greedy<5>(h, b, ga, d_penalties); break;
+            default: launch_greedy_wide(h->stream, b->d_planes, b->d_lens, b->n, b->w4, p->k, ga, d_penalties); break;
+        }
+    } else if (aligner == ASM_LEAP) {
+        if (unit && p->k >= 1 && p->k <= 5 && b->maxlen <= 256) {
+            switch (p->k) {
+                case 1: launch_leap_unit<1>(h, b, d_penalties); break;
+                case 2: launch_leap_unit<2>(h, b, d_penalties); break;
+                case 3: launch_leap_unit<3>(h, b, d_penalties); break;
+                case 4: launch_leap_unit<4>(h, b, d_penalties); break;
+                default: launch_leap_unit<5>(h, b, d_penalties); break;
+            }
+        } else {
+            launch_leap_wide(h->stream, b->d_planes, b->d_lens, b->n, b->w4, p->k, p->x, p->o, p->e, d_penalties);
+        }
+    } else {
+        if (unit) {
+            const dim3 g(grid_for(b->n)), t(ASM_BLOCK);
+            if (b->maxlen <= 128)
+                hipLaunchKernelGGL(nw_unit_kernel<2>, g, t, 0, h->stream, b->d_planes, b->d_lens, (long)b->n, b->w4, d_penalties);
+            else if (b->maxlen <= 256)
+                hipLaunchKernelGGL(nw_unit_kernel<4>, g, t, 0, h->stream, b->d_planes, b->d_lens, (long)b->n, b->w4, d_penalties);
+            else if (b->maxlen <= 384)
+                hipLaunchKernelGGL(nw_unit_kernel<6>, g, t, 0, h->stream, b->d_planes, b->d_lens, (long)b->n, b->w4, d_penalties);
+            else
+                hipLaunchKernelGGL(nw_unit_kernel<8>, g, t, 0, h->stream, b->d_planes, b->d_lens, (long)b->n, b->w4, d_penalties);
+        } else {
+            launch_nw_affine(h->stream, b->d_planes, b->d_lens, b->n, b->w4, b->maxlen, p->x, p->o, p->e, d_penalties);
+        }
+    }
+    HIPCHK(h, hipGetLastError());
+    return ASM_OK;
+}
+
+int asm_align_batch(asm_handle* h, int aligner, int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
+                    const uint32_t* ref_off, const asm_params* p, int greedy_mode, int32_t* penalties) {
+    if (!h || !penalties) return fail(h, ASM_EINVAL, "asm_align_batch: NULL argument");
+    int rc = check_params(h, aligner, p);
+    if (rc) return rc;
+    asm_batch* b = nullptr;
+    rc = asm_batch_upload(h, n, reads, read_off, refs, ref_off, greedy_mode, &b);
+    if (rc) return rc;
+    int32_t* d_out = nullptr;
+    if (hipMalloc((void**)&d_out, sizeof(int32_t) * (size_t)(n > 0 ? n : 1)) != hipSuccess) {
+        batch_release(b);
+        return fail(h, ASM_ENOMEM, "asm_align_batch: hipMalloc failed");
+    }
+    rc = asm_align_batch_async(h, b, aligner, p, d_out);
+    if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(h, ASM_ENODEVICE, "asm_align_batch: kernel failed");
+    if (!rc && n > 0 && hipMemcpy(penalties, d_out, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(h, ASM_ENODEVICE, "asm_align_batch: copy back failed");
+    (void)hipFree(d_out);
+    batch_release(b);
+    return rc;
+}
+
+int asm_count_equal_async(asm_handle* h, const int32_t* d_a, const int32_t* d_b, int64_t n, unsigned long long* d_count) {
+    if (!h || !d_a || !d_b || !d_count) return fail(h, ASM_EINVAL, "asm_count_equal_async: NULL argument");
+    if (n <= 0) return ASM_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    int64_t blocks = (n + ASM_BLOCK - 1) / ASM_BLOCK;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(count_equal_kernel, dim3((unsigned)blocks), dim3(ASM_BLOCK), 0, h->stream, d_a, d_b, (long)n, d_count);
+    HIPCHK(h, hipGetLastError());
+    return ASM_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------------- */
+int asm_device_malloc(asm_handle* h, size_t bytes, void** d_ptr) {
+    if (!h || !d_ptr) return fail(h, ASM_EINVAL, "asm_device_malloc: NULL argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMalloc(d_ptr, bytes ? bytes : 1));
+    return ASM_OK;
+}
+int asm_device_free(asm_handle* h, void* d_ptr) {
+    if (!h) return fail(h, ASM_EINVAL, "asm_device_free: NULL handle");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipFree(d_ptr));
+    return ASM_OK;
+}
+int asm_memcpy_d2h(asm_handle* h, void* dst, const void* d_src, size_t bytes) {
+    if (!h) return fail(h, ASM_EINVAL, "asm_memcpy_d2h: NULL handle");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return ASM_OK;
+}
+int asm_memcpy_h2d(asm_handle* h, void* d_dst, const void* src, size_t bytes) {
+    if (!h) return fail(h, ASM_EINVAL, "asm_memcpy_h2d: NULL handle");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+    return ASM_OK;
+}
+int asm_memset_async(asm_handle* h, void* d_ptr, int value, size_t bytes) {
+    if (!h) return fail(h, ASM_EINVAL, "asm_memset_async: NULL handle");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemsetAsync(d_ptr, value, bytes, h->stream));
+    return ASM_OK;
+}
+
+struct asm_timer {
+    hipEvent_t a, b;
+};
+int asm_timer_create(asm_handle* h, void** timer) {
+    if (!h || !timer) return fail(h, ASM_EINVAL, "asm_timer_create: NULL argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    asm_timer* t = new asm_timer;
+    HIPCHK(h, hipEventCreate(&t->a));
+    HIPCHK(h, hipEventCreate(&t->b));
+    *timer = t;
+    return ASM_OK;
+}
+int asm_timer_start(asm_handle* h, void* timer) {
+    if (!h || !timer) return fail(h, ASM_EINVAL, "asm_timer_start: NULL argument");
+    HIPCHK(h, hipEventRecord(((asm_timer*)timer)->a, h->stream));
+    return ASM_OK;
+}
+int asm_timer_stop(asm_handle* h, void* timer) {
+    if (!h || !timer) return fail(h, ASM_EINVAL, "asm_timer_stop: NULL argument");
+    HIPCHK(h, hipEventRecord(((asm_timer*)timer)->b, h->stream));
+    return ASM_OK;
+}
+int asm_timer_elapsed_ms(asm_handle* h, void* timer, float* ms) {
+    if (!h || !timer || !ms) return fail(h, ASM_EINVAL, "asm_timer_elapsed_ms: NULL argument");
+    asm_timer* t = (asm_timer*)timer;
+    HIPCHK(h, hipEventSynchronize(t->b));
+    HIPCHK(h, hipEventElapsedTime(ms, t->a, t->b));
+    return ASM_OK;
+}
+int asm_timer_destroy(asm_handle* h, void* timer) {
+    if (!timer) return ASM_OK;
+    asm_timer* t = (asm_timer*)timer;
+    (void)hipEventDestroy(t->a);
+    (void)hipEventDestroy(t->b);
+    delete t;
+    (void)h;
+    return ASM_OK;
+}
+
+} /* extern "C" */

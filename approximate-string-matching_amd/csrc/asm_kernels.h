@@ -1,0 +1,511 @@
+// HIP kernels of the batched pair aligner for MI355X (gfx950, wave64).
+//
+// Data layout in HBM: a batch of n pairs is held as
+//   planes : uint4[4][w4][n]   plane p in {A.bit0, A.bit1, B.bit0, B.bit1}, granule g = positions
+//                              [128g, 128g+128), pair i at planes[(p*w4+g)*n + i]  (bit q of a granule <->
+//                              character 128g+q; codes A=00 C=01 G=10 T=11, anything else 00 — the code of
+//                              GASMA/bit_convert.cpp:340-355)
+//   lens   : uint32[n]         m | n << 16
+// so that thread i of a wave reads 16 contiguous bytes next to thread i+1's: every load instruction of a
+// thread-per-pair kernel is one fully coalesced 1 KiB request.
+//
+// Work decomposition: ONE THREAD PER READ PAIR for the narrow band (k <= 7, the benchmark's k = 3): the
+// 2k+1 lanes of the band live in registers, the lane loops are fully unrolled, no cross-lane traffic, and
+// every VALU lane does useful work (a wave-per-pair mapping would idle 57 of 64 lanes at k = 3).  Wide bands
+// (k up to 50) use the block-per-pair kernels further down (thread = band lane).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "asm_bits.h"
+#include "asm_gen.h"
+
+#define ASM_BLOCK 256
+
+// --------------------------------------------------------------------------------------------------------
+// Pack: ASCII -> bit planes.  Device counterpart of sse3_convert2bit1 (GASMA/bit_convert.cpp:248-369), minus
+// its in-place byte permutation (whose only observable effect, the stale tails of later pairs, is supplied
+// through `tails` in sequential mode — see asm_tails.h).  One wave per pair: lane l looks at characters l and
+// l+64 of a granule for both strings, and four __ballot()s per half produce 64 bits of each plane at once.
+// --------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ASM_BLOCK) void pack_kernel(const char* __restrict__ reads,
+                                                         const uint32_t* __restrict__ read_off,
+                                                         const char* __restrict__ refs,
+                                                         const uint32_t* __restrict__ ref_off,
+                                                         const uint4* __restrict__ tails, /* [4][n] or null */
+                                                         uint4* __restrict__ planes, uint32_t* __restrict__ lens,
+                                                         long n, int w4) {
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long i = wave; i < n; i += nwaves) {
+        const uint32_t ra = read_off[i], rb = ref_off[i];
+        const int m = (int)(read_off[i + 1] - ra), nn = (int)(ref_off[i + 1] - rb);
+        if (lane == 0) lens[i] = (uint32_t)m | ((uint32_t)nn << 16);
+        for (int g = 0; g < w4; g++) {
+            u64 bits[4][2];
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const int pos = g * 128 + half * 64 + lane;
+                const char ca = pos < m ? reads[ra + pos] : (char)0;
+                const char cb = pos < nn ? refs[rb + pos] : (char)0;
+                bits[0][half] = __ballot(ca == 'C' || ca == 'T');
+                bits[1][half] = __ballot(ca == 'G' || ca == 'T');
+                bits[2][half] = __ballot(cb == 'C' || cb == 'T');
+                bits[3][half] = __ballot(cb == 'G' || cb == 'T');
+            }
+            if (lane < 4) {
+                u64 lo = lane == 0 ? bits[0][0] : lane == 1 ? bits[1][0] : lane == 2 ? bits[2][0] : bits[3][0];
+                u64 hi = lane == 0 ? bits[0][1] : lane == 1 ? bits[1][1] : lane == 2 ? bits[2][1] : bits[3][1];
+                uint4 q = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+                if (tails != nullptr && g == 0) {
+                    const uint4 t = tails[(long)lane * n + i];
+                    q.x |= t.x, q.y |= t.y, q.z |= t.z, q.w |= t.w;
+                }
+                planes[((long)lane * w4 + g) * n + i] = q;
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------
+// Greedy hurdle-matrix aligner, GLOBAL mode, band lanes -K..K in registers, one thread per pair.
+// Follows hurdle_matrix<int_128bit>: _construct_hurdles (hurdle_matrix.h:441-455), _update_highway_list
+// (:285-362), _choose_best_highway (:368-401), _step (:407-434), run (:568-597).  The per-lane cache
+// {starting_point,length,num_switches} persists across steps exactly as highway_info does (:26-44).
+// --------------------------------------------------------------------------------------------------------
+struct GreedyArgs {
+    int x, o, e;
+    double sig_match, sig_mismatch, sig_indel; /* hurdle_matrix.h:536-538, computed on the host with libm */
+};
+
+ASM_DEV V128 greedy_lane_vector(V128 A0, V128 A1, V128 B0, V128 B1, int lane) {
+    const int s = lane < 0 ? -lane : lane;
+    V128 m0, m1;
+    if (lane < 0) {
+        m0 = v_xor(v_toward0(A0, s), B0);
+        m1 = v_xor(v_toward0(A1, s), B1);
+    } else {
+        m0 = v_xor(v_toward0(B0, s), A0);
+        m1 = v_xor(v_toward0(B1, s), A1);
+    }
+    return v_or(m0, m1);
+}
+
+template <int K>
+__global__ __launch_bounds__(ASM_BLOCK) void greedy_kernel(const uint4* __restrict__ planes,
+                                                           const uint32_t* __restrict__ lens, long n, int w4,
+                                                           GreedyArgs args, int32_t* __restrict__ out) {
+    constexpr int NL = 2 * K + 1;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const V128 A0 = v_from_uint4(planes[((long)0 * w4) * n + i]);
+    const V128 A1 = v_from_uint4(planes[((long)1 * w4) * n + i]);
+    const V128 B0 = v_from_uint4(planes[((long)2 * w4) * n + i]);
+    const V128 B1 = v_from_uint4(planes[((long)3 * w4) * n + i]);
+    const uint32_t ln = lens[i];
+    int m = (int)(ln & 0xffffu), nn = (int)(ln >> 16);
+    m = m > 128 ? 128 : m; /* hurdle_matrix.h:626-627 */
+    nn = nn > 128 ? 128 : nn;
+    const int x = args.x, o = args.o, e = args.e;
+    const int dest_lane = nn - m; /* hurdle_matrix.h:649 */
+
+    V128 lo_[NL], lf_[NL];
+    int sp[NL], len[NL], nsw[NL], dst[NL], sw[NL], nh[NL];
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+        const int lane = j - K;
+        lo_[j] = greedy_lane_vector(A0, A1, B0, B1, lane);
+        lf_[j] = v_flip_short_hurdles1(lo_[j]);
+        sp[j] = -1; /* hurdle_matrix.h:106-119 */
+        len[j] = 0;
+        nsw[j] = 128;
+        dst[j] = lane_destination(m, nn, lane);
+        sw[j] = nh[j] = 128;
+    }
+
+    int cur_lane = 0, cur_col = 0, cost = 0;
+    for (int guard = 0; guard < 4 * 128; guard++) {
+        // ---- _update_highway_list ----
+        bool reaching = false;
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            const int lane = j - K;
+            const int start_col = cur_col + fwd_col(cur_lane, lane);
+            if (sp[j] < start_col) {
+                int d = lane - cur_lane;
+                nsw[j] = d < 0 ? -d : d;
+                const V128 l = v_toward0(lf_[j], start_col);
+                const int fz = v_first_zero(l);
+                const int nx = v_first_one(v_toward0(l, fz));
+                sp[j] = start_col + fz;
+                len[j] = nx;
+                if (start_col + fz + nx > dst[j]) {
+                    const int c = dst[j] - (start_col + fz);
+                    len[j] = c > 0 ? c : 0;
+                    reaching = true;
+                }
+            }
+            sw[j] = lane_penalty(cur_lane, lane, o, e);
+            nh[j] = v_pop_between(lo_[j], start_col, sp[j] + len[j]);
+        }
+        double best_h = -__builtin_inf();
+        int best_leap = 0; /* -numeric_limits<int>::infinity() == 0 (hurdle_matrix.h:287) */
+        int best = 0, best_sp = 0, best_len = 0, best_cost = 0;
+        V128 best_vec = v_make(0, 0);
+        bool have = false;
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            const int lane = j - K;
+            const int hc = x * nh[j];
+            const int cur_cost = -sw[j] - hc;
+            // no FMA contraction: identical bits on every compiler/target (oracle is built -ffp-contract=off)
+            double heur = __dadd_rn(__dadd_rn(__dmul_rn(args.sig_match, (double)len[j]),
+                                              __dmul_rn(args.sig_mismatch, (double)nh[j])),
+                                    __dmul_rn(args.sig_indel, (double)nsw[j]));
+            int leap = -sw[j];
+            if (reaching) {
+                const int fsw = lane_penalty(lane, dest_lane, o, e);
+                heur = (double)(cur_cost - fsw - x * (dst[j] - sp[j] - len[j]));
+                leap -= fsw;
+            }
+            const bool take = heur > best_h || (heur == best_h && leap > best_leap);
+            if (take) {
+                best_h = heur;
+                best_leap = leap;
+                best = lane;
+                best_sp = sp[j];
+                best_len = len[j];
+                best_cost = hc + sw[j];
+                best_vec = lo_[j];
+                have = true;
+            }
+        }
+        // When no lane ever wins (cannot happen: the first lane beats -inf) the reference's best lane is
+        // lane 0; keep that behaviour for completeness.
+        if (!have) {
+            best = 0;
+            best_sp = sp[K];
+            best_len = len[K];
+            best_cost = x * nh[K] + sw[K];
+            best_vec = lo_[K];
+        }
+        if (best_len <= 0) break; /* hurdle_matrix.h:358-361 */
+
+        // ---- _choose_best_highway ----
+        int small_inter = best_cost, small_total = best_cost;
+        int ch = best, ch_sp = best_sp, ch_len = best_len, ch_cost = best_cost;
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            const int lane = j - K;
+            if (lane != best && !(sp[j] + fwd_col(lane, best) > best_sp)) {
+                const int endp = sp[j] + len[j];
+                const int inter = sw[j] + v_pop_between(lo_[j], cur_col + fwd_col(cur_lane, lane), endp);
+                const int tail = x * v_pop_between(best_vec, fwd_col(lane, best) + endp, best_sp);
+                const int total = inter + lane_penalty(lane, best, o, e) + (tail > 0 ? tail : 0);
+                if (total <= small_total && inter <= small_inter) {
+                    small_total = total;
+                    small_inter = inter;
+                    ch = lane;
+                    ch_sp = sp[j];
+                    ch_len = len[j];
+                    ch_cost = sw[j] + x * nh[j];
+                }
+            }
+        }
+        // ---- _step commit (hurdle_matrix.h:411-433) ----
+        cost += ch_cost;
+        cur_lane = ch;
+        cur_col = ch_sp + ch_len;
+        if (cur_col >= lane_destination(m, nn, ch)) break;
+    }
+    // ---- final hop (hurdle_matrix.h:575-590); the destination lane vector is built directly (it may lie
+    // outside the band: own behaviour for the reference's undefined case) ----
+    const int dest_col = lane_destination(m, nn, dest_lane);
+    if (cur_lane != dest_lane || cur_col < dest_col) {
+        const V128 dv = greedy_lane_vector(A0, A1, B0, B1, dest_lane);
+        const int sw_f = lane_penalty(cur_lane, dest_lane, o, e);
+        const int distance = v_pop_between(dv, cur_col + fwd_col(cur_lane, dest_lane), dest_col);
+        const int hc = x * distance;
+        cost += sw_f + (hc > 0 ? hc : 0);
+    }
+    out[i] = cost;
+}
+
+// --------------------------------------------------------------------------------------------------------
+// LEAP (banded affine Landau-Vishkin, "BAG"), unit penalties x = o = e = 1, lanes in registers, one thread
+// per pair.  Follows LV::run (LEAP_SIMD/LV_BAG.cpp:127-245) with init(k,200,ED_GLOBAL,1,1,1); the scalar
+// character loop count_ID_length (:9-23) becomes a count-trailing-zeros on the lane's mismatch bit-vector.
+// Only generation e-1 is live, so three registers per lane replace the four [2k+3][201]
+// tables.  W64 = number of 64-bit words per vector (2: len <= 128, 4: len <= 256).
+// --------------------------------------------------------------------------------------------------------
+template <int W64>
+struct VW {
+    u64 w[W64];
+};
+
+// first set bit at or after `from` in a W64-word vector, or W64*64 when none.  `from` in [0, W64*64].
+template <int W64>
+ASM_DEV int vw_next_one(const VW<W64>& v, int from) {
+    int res = W64 * 64;
+#pragma unroll
+    for (int q = W64 - 1; q >= 0; q--) {
+        const int base = q * 64;
+        const int rel = from - base; /* bits below `from` are ignored */
+        u64 word = v.w[q];
+        u64 msk = rel <= 0 ? ~0ull : (rel >= 64 ? 0ull : (~0ull << rel));
+        word &= msk;
+        if (word) res = base + __builtin_ctzll(word);
+    }
+    return res;
+}
+
+// bit p of the result = bit (p - s) of v (bits move away from index 0), s in [0, 63]
+template <int W64>
+ASM_DEV VW<W64> vw_away0_small(const VW<W64>& v, int s) {
+    VW<W64> r;
+#pragma unroll
+    for (int q = 0; q < W64; q++) {
+        u64 lo = q > 0 ? v.w[q - 1] : 0ull;
+        r.w[q] = (v.w[q] << s) | (s ? (lo >> (64 - s)) : 0ull);
+    }
+    return r;
+}
+
+template <int W64>
+ASM_DEV VW<W64> vw_low_ones(int len) {
+    VW<W64> r;
+#pragma unroll
+    for (int q = 0; q < W64; q++) {
+        const int rel = len - q * 64;
+        r.w[q] = rel <= 0 ? 0ull : (rel >= 64 ? ~0ull : ((1ull << rel) - 1ull));
+    }
+    return r;
+}
+
+template <int W64>
+ASM_DEV void load_planes(const uint4* __restrict__ planes, long n, int w4, long i, VW<W64>& A0, VW<W64>& A1,
+                         VW<W64>& B0, VW<W64>& B1) {
+#pragma unroll
+    for (int g = 0; g < W64 / 2; g++) {
+        if (g >= w4) { /* vector wider than the batch's granule count: upper words are empty */
+            A0.w[2 * g] = A0.w[2 * g + 1] = A1.w[2 * g] = A1.w[2 * g + 1] = 0ull;
+            B0.w[2 * g] = B0.w[2 * g + 1] = B1.w[2 * g] = B1.w[2 * g + 1] = 0ull;
+            continue;
+        }
+        uint4 q;
+        q = planes[((long)0 * w4 + g) * n + i];
+        A0.w[2 * g] = (u64)q.x | ((u64)q.y << 32), A0.w[2 * g + 1] = (u64)q.z | ((u64)q.w << 32);
+        q = planes[((long)1 * w4 + g) * n + i];
+        A1.w[2 * g] = (u64)q.x | ((u64)q.y << 32), A1.w[2 * g + 1] = (u64)q.z | ((u64)q.w << 32);
+        q = planes[((long)2 * w4 + g) * n + i];
+        B0.w[2 * g] = (u64)q.x | ((u64)q.y << 32), B0.w[2 * g + 1] = (u64)q.z | ((u64)q.w << 32);
+        q = planes[((long)3 * w4 + g) * n + i];
+        B1.w[2 * g] = (u64)q.x | ((u64)q.y << 32), B1.w[2 * g + 1] = (u64)q.z | ((u64)q.w << 32);
+    }
+}
+
+// Mismatch vector of LEAP lane d = l - mid (LV_BAG.cpp:13-18): position p = max(read idx, ref idx);
+// d < 0 compares A[p-|d|] with B[p], d > 0 compares A[p] with B[p-d].  Positions where either string has
+// run out (the NUL padding of LV::load_reads, LV_BAG.cpp:116-117) and all positions >= len are mismatches.
+template <int W64>
+ASM_DEV VW<W64> leap_lane_mask(const VW<W64>& A0, const VW<W64>& A1, const VW<W64>& B0, const VW<W64>& B1,
+                               const VW<W64>& VA, const VW<W64>& VB, int d) {
+    VW<W64> r;
+    const int s = d < 0 ? -d : d;
+    if (d < 0) {
+        VW<W64> a0 = vw_away0_small<W64>(A0, s), a1 = vw_away0_small<W64>(A1, s), va = vw_away0_small<W64>(VA, s);
+#pragma unroll
+        for (int q = 0; q < W64; q++) r.w[q] = (a0.w[q] ^ B0.w[q]) | (a1.w[q] ^ B1.w[q]) | ~(va.w[q] & VB.w[q]);
+    } else {
+        VW<W64> b0 = vw_away0_small<W64>(B0, s), b1 = vw_away0_small<W64>(B1, s), vb = vw_away0_small<W64>(VB, s);
+#pragma unroll
+        for (int q = 0; q < W64; q++) r.w[q] = (A0.w[q] ^ b0.w[q]) | (A1.w[q] ^ b1.w[q]) | ~(VA.w[q] & vb.w[q]);
+    }
+    return r;
+}
+
+template <int K, int W64>
+__global__ __launch_bounds__(ASM_BLOCK) void leap_unit_kernel(const uint4* __restrict__ planes,
+                                                              const uint32_t* __restrict__ lens, long n, int w4,
+                                                              int32_t* __restrict__ out) {
+    constexpr int NL = 2 * K + 1;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t ln = lens[i];
+    const int m = (int)(ln & 0xffffu), nn = (int)(ln >> 16);
+    const int len = m > nn ? m : nn; /* benchmark_utils.h:162 */
+    VW<W64> A0, A1, B0, B1;
+    load_planes<W64>(planes, n, w4, i, A0, A1, B0, B1);
+    const VW<W64> VA = vw_low_ones<W64>(m), VB = vw_low_ones<W64>(nn);
+
+    VW<W64> mask[NL];
+#pragma unroll
+    for (int j = 0; j < NL; j++) mask[j] = leap_lane_mask<W64>(A0, A1, B0, B1, VA, VB, j - K);
+
+    // generation e-1 state per lane: end, I_pos, D_pos (-2 = never reached, LV_BAG.cpp:95-101)
+    int en[NL], ip[NL], dp[NL];
+#pragma unroll
+    for (int j = 0; j < NL; j++) en[j] = ip[j] = dp[j] = -2;
+
+    int result = -1;
+    // e = 0: only the main diagonal is live in ED_GLOBAL (LV_BAG.cpp:102-104,131-147)
+    {
+        int e0 = vw_next_one<W64>(mask[K], 0);
+        e0 = e0 > len ? len : e0;
+        en[K] = e0;
+        if (e0 == len) result = 0;
+    }
+    for (int e = 1; e <= ASM_LEAP_AF_THRESHOLD && result < 0; e++) {
+        int en2[NL], ip2[NL], dp2[NL];
+        bool pass = false;
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            const int d = j - K;
+            const int top = d >= 0 ? 1 : 0, bot = d <= 0 ? 1 : 0;
+            const int e_up = j > 0 ? en[j - 1] : -2, i_up = j > 0 ? ip[j - 1] : -2;
+            const int e_dn = j < NL - 1 ? en[j + 1] : -2, d_dn = j < NL - 1 ? dp[j + 1] : -2;
+            int inew = -2, dnew = -2;
+            if (e_up >= 0 && e_up > i_up)
+                inew = e_up + top; /* LV_BAG.cpp:166-167 */
+            else if (i_up >= 0)
+                inew = i_up + top; /* :172-176 */
+            if (e_dn >= 0 && e_dn > d_dn)
+                dnew = e_dn + bot; /* :179-180 */
+            else if (d_dn >= 0)
+                dnew = d_dn + bot; /* :181-182 */
+            int st = en[j] >= 0 ? en[j] + 1 : -2; /* :186-187 */
+            st = inew > st ? inew : st;           /* :193-194 */
+            st = dnew > st ? dnew : st;           /* :200-201 */
+            int enew = -2;
+            if (st >= 0) {
+                const int from = st > len ? len : st;
+                int t = vw_next_one<W64>(mask[j], from); /* count_ID_length, :9-23 */
+                t = t > len ? len : t;
+                enew = st > len ? st : t;
+                if (enew == len) { /* :220-238 */
+                    const int diff = d < 0 ? -d : d;
+                    const int conv = e + diff; /* o + (diff-1)*ext with o = ext = 1 */
+                    if (conv <= ASM_LEAP_AF_THRESHOLD) pass = true;
+                }
+            }
+            en2[j] = enew, ip2[j] = inew, dp2[j] = dnew;
+        }
+#pragma unroll
+        for (int j = 0; j < NL; j++) en[j] = en2[j], ip[j] = ip2[j], dp[j] = dp2[j];
+        if (pass) result = e; /* final_ED (LV_BAG.cpp:228,356-358), not converge_ED */
+    }
+    out[i] = result;
+}
+
+// --------------------------------------------------------------------------------------------------------
+// NW for unit penalties (x = o = e = 1): global edit distance by the Myers/Hyyro bit-parallel recurrence —
+// the column of vertical deltas of the DP matrix lives in bit-vectors, one thread per pair, the read is the
+// vertical string.  Gives exactly the penalty parasail's NW returns for these scores (benchmark_utils.h:
+// 139-142,288 with matrix (0,-1), open = extend = 1, i.e. Levenshtein distance).
+// --------------------------------------------------------------------------------------------------------
+template <int W64>
+__global__ __launch_bounds__(ASM_BLOCK) void nw_unit_kernel(const uint4* __restrict__ planes,
+                                                            const uint32_t* __restrict__ lens, long n, int w4,
+                                                            int32_t* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t ln = lens[i];
+    const int m = (int)(ln & 0xffffu), nn = (int)(ln >> 16);
+    VW<W64> A0, A1, B0, B1;
+    load_planes<W64>(planes, n, w4, i, A0, A1, B0, B1);
+    const VW<W64> VA = vw_low_ones<W64>(m);
+    VW<W64> Pv, Mv;
+#pragma unroll
+    for (int q = 0; q < W64; q++) Pv.w[q] = ~0ull, Mv.w[q] = 0ull;
+    int score = m;
+    if (m == 0) {
+        out[i] = nn;
+        return;
+    }
+    const int top_word = (m - 1) >> 6;
+    const u64 top_bit = 1ull << ((m - 1) & 63);
+    for (int j = 0; j < nn; j++) {
+        // code of text character j, broadcast to all bits
+        u64 t0 = 0, t1 = 0;
+#pragma unroll
+        for (int q = 0; q < W64; q++) {
+            if ((j >> 6) == q) {
+                t0 = (B0.w[q] >> (j & 63)) & 1ull;
+                t1 = (B1.w[q] >> (j & 63)) & 1ull;
+            }
+        }
+        const u64 T0 = 0ull - t0, T1 = 0ull - t1;
+        u64 carry = 0, ph_in = 1ull, mh_in = 0ull; /* ph_in = 1: D[0][j] = j (global alignment) */
+        int delta = 0;
+#pragma unroll
+        for (int q = 0; q < W64; q++) {
+            const u64 Eq = ~(A0.w[q] ^ T0) & ~(A1.w[q] ^ T1) & VA.w[q];
+            const u64 pv = Pv.w[q], mv = Mv.w[q];
+            const u64 Xv = Eq | mv;
+            const u64 x1 = Eq & pv;
+            const u64 s1 = x1 + pv;
+            const u64 c1 = s1 < x1 ? 1ull : 0ull;
+            const u64 s2 = s1 + carry;
+            const u64 c2 = s2 < s1 ? 1ull : 0ull;
+            carry = c1 | c2;
+            const u64 Xh = (s2 ^ pv) | Eq;
+            u64 Ph = mv | ~(Xh | pv);
+            u64 Mh = pv & Xh;
+            if (q == top_word) {
+                delta = (Ph & top_bit) ? 1 : ((Mh & top_bit) ? -1 : 0);
+            }
+            const u64 ph_out = Ph >> 63, mh_out = Mh >> 63;
+            Ph = (Ph << 1) | ph_in;
+            Mh = (Mh << 1) | mh_in;
+            ph_in = ph_out, mh_in = mh_out;
+            Pv.w[q] = Mh | ~(Xv | Ph);
+            Mv.w[q] = Ph & Xv;
+        }
+        score += delta;
+    }
+    out[i] = score;
+}
+
+// accuracy counter (benchmark_utils.h:253-255)
+__global__ __launch_bounds__(ASM_BLOCK) void count_equal_kernel(const int32_t* __restrict__ a,
+                                                                const int32_t* __restrict__ b, long n,
+                                                                unsigned long long* __restrict__ count) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    unsigned int local = 0;
+    for (; i < n; i += stride) local += (a[i] == b[i]) ? 1u : 0u;
+    // wave reduction, then one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(count, (unsigned long long)local);
+}
+
+// --------------------------------------------------------------------------------------------------------
+// Device generator (asm_batch_generate): same inline code as the host generator (asm_gen.h).
+// --------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ASM_BLOCK) void gen_lengths_kernel(asm_gen_config cfg, long first, long n,
+                                                                uint32_t* __restrict__ mlen,
+                                                                uint32_t* __restrict__ nlen) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int m, nn;
+    asm_gen_lengths(&cfg, (uint64_t)(first + i), &m, &nn);
+    mlen[i] = (uint32_t)m;
+    nlen[i] = (uint32_t)nn;
+}
+
+__global__ __launch_bounds__(64) void gen_fill_kernel(asm_gen_config cfg, long first, long n,
+                                                      const uint32_t* __restrict__ read_off,
+                                                      const uint32_t* __restrict__ ref_off,
+                                                      char* __restrict__ reads, char* __restrict__ refs) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    char rd[ASM_MAX_LENGTH + 8];
+    char tx[ASM_GEN_MAX_TEXT];
+    int m, nn;
+    asm_gen_pair(&cfg, (uint64_t)(first + i), rd, tx, &m, &nn);
+    char* r = reads + read_off[i];
+    char* t = refs + ref_off[i];
+    for (int j = 0; j < m; j++) r[j] = rd[j];
+    for (int j = 0; j < nn; j++) t[j] = tx[j];
+}

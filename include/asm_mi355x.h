@@ -1,0 +1,147 @@
+/* asm_mi355x.h — C ABI of the MI355X-native batched pair aligner (libasm_mi355x.so).
+ *
+ * Drop-in boundary for ONE path of GZHoffie/approximate-string-matching: the per-pair work of its benchmark
+ * harness, `benchmark::_run_benchmark` (GASMA/benchmark/benchmark_utils.h:231-259), i.e.
+ *   NW     `_run_nw_sse`  benchmark_utils.h:130-150  (parasail_nw_trace_striped_sse41_128_16; penalty = -score)
+ *   LEAP   `_run_LEAP`    benchmark_utils.h:156-179  (LV::load_reads/reset/run/get_ED, LEAP_SIMD/LV_BAG.cpp:110-245,356)
+ *   Greedy `_run_greedy`  benchmark_utils.h:185-201  (hurdle_matrix<int_128bit>::reset/run/get_cost, hurdle_matrix.h:568,625,677)
+ * plus the accuracy counters of benchmark_utils.h:249-255 and the input definition of benchmark_dataset.h.
+ * The reference runs these one pair at a time on one CPU thread; this library runs a whole batch of pairs
+ * per call on one GPU.  Plain pointers and sizes only; no C++/torch types cross this boundary.
+ *
+ * Batch layout: `reads`/`refs` = concatenated ASCII (no terminators); `read_off`/`ref_off` = n+1 prefix
+ * offsets (uint32); pair i = reads[read_off[i] .. read_off[i+1]) vs refs[ref_off[i] .. ref_off[i+1]).
+ *
+ * Threading: one handle per GPU; calls on one handle must be serialised by the caller.  Calls are
+ * synchronous at return unless the name ends in `_async` (those only enqueue on the handle's stream).
+ * Every function returns 0 on success or a negative ASM_E* code; asm_last_error() gives the message.
+ * There is NO CPU fallback: without a usable HIP device every compute entry point fails with ASM_ENODEVICE.
+ */
+#ifndef ASM_MI355X_H
+#define ASM_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASM_OK 0
+#define ASM_EINVAL (-1)    /* bad argument (k out of range, o < e for LEAP, NULL pointer, ...)            */
+#define ASM_ENODEVICE (-2) /* no HIP device / device call failed                                          */
+#define ASM_ENOMEM (-3)
+#define ASM_EUNSUPPORTED (-4) /* e.g. sequence longer than the kernels' compiled limit                    */
+
+/* aligner ids — the three aligners `_run_benchmark` runs per pair */
+#define ASM_NW 0
+#define ASM_LEAP 1
+#define ASM_GREEDY 2
+
+/* Greedy buffer-tail mode (hurdle_matrix.h:136-137,625-631 + bit_convert.cpp:265-330) */
+#define ASM_GREEDY_SEQUENTIAL 0 /* reference as run: stale bytes of earlier pairs flow into later ones   */
+#define ASM_GREEDY_CLEAN 1      /* tail bytes are NUL for every pair (order independent)                  */
+
+/* reference limits reproduced here */
+#define ASM_GREEDY_MAX_LENGTH 128 /* GASMA/utils.h:23-25 — Greedy aligns the first 128 bases            */
+#define ASM_GREEDY_MAX_K 50       /* GASMA/hurdle_matrix.h:8                                             */
+#define ASM_LEAP_MAX_LENGTH 256   /* LEAP_SIMD/LV_BAG.h:17-18; longer pairs are undefined in the reference */
+#define ASM_LEAP_AF_THRESHOLD 200 /* benchmark_utils.h:289                                               */
+#define ASM_MAX_LENGTH 512        /* longest sequence any kernel here accepts                            */
+
+typedef struct asm_handle asm_handle; /* one per GPU: device id, stream, scratch                          */
+typedef struct asm_batch asm_batch;   /* a device-resident batch of read pairs (ASCII + packed bit planes) */
+
+/* Scoring and aligner parameters — the constructor arguments of `benchmark` (benchmark_utils.h:263-289)
+ * and of hurdle_matrix (hurdle_matrix.h:552-559). */
+typedef struct asm_params {
+    int32_t k;           /* band half-width (lanes -k..k)                                                 */
+    int32_t x, o, e;     /* mismatch, gap-open (first gap base), gap-extend penalties, all >= 0           */
+    double p_match;      /* Greedy significance model; defaults 0.80, 0.20/3, 0.40/3                      */
+    double p_mismatch;
+    double p_indel;
+} asm_params;
+
+/* ---- library / handle ------------------------------------------------------------------------------ */
+const char* asm_version(void);
+void asm_default_params(asm_params* p);          /* x=o=e=1, k=3, default probabilities (benchmark.cpp:22) */
+int asm_device_count(void);                       /* number of HIP devices (0 without a GPU; never fails)   */
+int asm_create(asm_handle** out, int device);     /* binds the handle to HIP device `device`               */
+int asm_destroy(asm_handle* h);
+const char* asm_last_error(const asm_handle* h);  /* h may be NULL: last error of the calling thread       */
+/* Launch everything on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the
+ * handle's own stream. */
+int asm_set_stream(asm_handle* h, void* hip_stream);
+int asm_synchronize(asm_handle* h);
+
+/* ---- input definition: seeded restatement of `Dataset` (benchmark_dataset.h:61-253) ---- */
+#define ASM_GEN_EXACT_ERRORS 0 /* exactly ceil(L*err) edit operations per pair (Dataset exact=true)        */
+#define ASM_GEN_PER_BASE 1     /* independent per-base substitution / insertion / deletion (SRR611076-shaped) */
+typedef struct asm_gen_config {
+    uint64_t seed;
+    int32_t kind;
+    int32_t len_lo, len_hi; /* read length uniform in [len_lo, len_hi]                                     */
+    float err;              /* ASM_GEN_EXACT_ERRORS: error rate                                           */
+    float mismatch_rate;    /* ASM_GEN_EXACT_ERRORS: P(edit is a substitution); Dataset uses 0.96         */
+    float p_sub, p_ins, p_del; /* ASM_GEN_PER_BASE rates per base                                         */
+} asm_gen_config;
+/* Host generator.  Pairs [first, first+n) of the seeded stream (every pair has its own counter-based RNG
+ * state, so any slice can be generated independently — this is how shards get their part).
+ * With reads == NULL only the offsets are produced (sizing pass). */
+int asm_generate_pairs(const asm_gen_config* cfg, int64_t first, int64_t n, uint32_t* read_off,
+                       uint32_t* ref_off, char* reads, size_t reads_cap, char* refs, size_t refs_cap);
+
+/* ---- device-resident batches ------------------------------------------------------------------------- */
+/* Copies the ASCII batch to the GPU and packs it (pack kernel: ASCII -> 2 bit planes per string, the
+ * device counterpart of sse3_convert2bit1, bit_convert.cpp:248-369).  greedy_mode selects what the bit
+ * planes hold beyond each string's end (the bytes Greedy's conversion would see). */
+int asm_batch_upload(asm_handle* h, int64_t n, const char* reads, const uint32_t* read_off,
+                     const char* refs, const uint32_t* ref_off, int greedy_mode, asm_batch** out);
+/* Generates pairs [first, first+n) of the seeded stream directly in HBM (device generator; bit-identical
+ * to asm_generate_pairs) and packs them: no PCIe traffic. */
+int asm_batch_generate(asm_handle* h, const asm_gen_config* cfg, int64_t first, int64_t n, int greedy_mode,
+                       asm_batch** out);
+int asm_batch_free(asm_handle* h, asm_batch* b);
+int64_t asm_batch_size(const asm_batch* b);
+int asm_batch_max_length(const asm_batch* b);
+/* Copies the batch's ASCII form back to the host (buffers sized by the caller from the offsets). */
+int asm_batch_download(asm_handle* h, const asm_batch* b, uint32_t* read_off, uint32_t* ref_off,
+                       char* reads, size_t reads_cap, char* refs, size_t refs_cap);
+/* Re-runs only the pack kernel on the batch's resident ASCII (enqueue only). */
+int asm_batch_pack_async(asm_handle* h, asm_batch* b);
+
+/* ---- the hot path -------------------------------------------------------------------------------------- */
+/* One aligner over a resident batch; d_penalties = DEVICE pointer to n int32 (enqueue only).
+ * Replaces, per pair: ASM_NW -> -parasail score (benchmark_utils.h:139-142); ASM_LEAP -> LV::get_ED()
+ * (LV_BAG.cpp:356; -1 where no lane passes within 200); ASM_GREEDY -> hurdle_matrix::get_cost()
+ * (hurdle_matrix.h:677). */
+int asm_align_batch_async(asm_handle* h, const asm_batch* b, int aligner, const asm_params* p,
+                          int32_t* d_penalties);
+/* Convenience: host in, host out (upload + pack + align + copy back).  The reference-shaped call:
+ * align(read, ref, k) for every pair of the batch. */
+int asm_align_batch(asm_handle* h, int aligner, int64_t n, const char* reads, const uint32_t* read_off,
+                    const char* refs, const uint32_t* ref_off, const asm_params* p, int greedy_mode,
+                    int32_t* penalties);
+/* accuracy counter of benchmark_utils.h:253-255: *d_count += #{i : a[i] == b[i]} (device pointers; enqueue
+ * only; the caller zeroes *d_count). */
+int asm_count_equal_async(asm_handle* h, const int32_t* d_a, const int32_t* d_b, int64_t n,
+                          unsigned long long* d_count);
+
+/* ---- plain device memory helpers (so that non-torch hosts can drive the async API) --------------------- */
+int asm_device_malloc(asm_handle* h, size_t bytes, void** d_ptr);
+int asm_device_free(asm_handle* h, void* d_ptr);
+int asm_memcpy_d2h(asm_handle* h, void* dst, const void* d_src, size_t bytes);
+int asm_memcpy_h2d(asm_handle* h, void* d_dst, const void* src, size_t bytes);
+int asm_memset_async(asm_handle* h, void* d_ptr, int value, size_t bytes);
+
+/* ---- timing helper: HIP events on the handle's stream (bench.py measures kernels with these) ----------- */
+int asm_timer_create(asm_handle* h, void** timer);
+int asm_timer_start(asm_handle* h, void* timer);
+int asm_timer_stop(asm_handle* h, void* timer);
+int asm_timer_elapsed_ms(asm_handle* h, void* timer, float* ms); /* synchronises on the stop event */
+int asm_timer_destroy(asm_handle* h, void* timer);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASM_MI355X_H */

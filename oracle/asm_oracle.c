@@ -1,0 +1,671 @@
+/* TEST INFRASTRUCTURE ONLY — see asm_oracle.h.  Plain C restatement of the reference hot path.
+ * Every function cites the reference lines it follows; nothing here is copied from them. */
+#include "asm_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static int g_threads = 1;
+
+int orc_set_threads(int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    g_threads = nthreads;
+    return g_threads;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * 128-bit little-endian bit vector (GASMA/utils.h:49-271, class int_128bit).
+ * The reference's "shift_left" moves bits TOWARD index 0 and "shift_right" away from it; both return 0
+ * for counts outside [0,127] (utils.h:131-153: the per-64-bit SSE shifts zero on counts > 63 and a
+ * negative int count is seen as a huge unsigned one).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    uint64_t lo, hi;
+} v128;
+
+static inline v128 v_zero(void) {
+    v128 r = {0, 0};
+    return r;
+}
+
+static inline v128 v_toward0(v128 v, int s) { /* utils.h:143-153 shift_left */
+    v128 r;
+    if (s < 0 || s >= 128) return v_zero();
+    if (s >= 64) {
+        r.lo = v.hi >> (s - 64);
+        r.hi = 0;
+    } else if (s == 0) {
+        r = v;
+    } else {
+        r.lo = (v.lo >> s) | (v.hi << (64 - s));
+        r.hi = v.hi >> s;
+    }
+    return r;
+}
+
+static inline v128 v_away0(v128 v, int s) { /* utils.h:131-141 shift_right */
+    v128 r;
+    if (s < 0 || s >= 128) return v_zero();
+    if (s >= 64) {
+        r.hi = v.lo << (s - 64);
+        r.lo = 0;
+    } else if (s == 0) {
+        r = v;
+    } else {
+        r.hi = (v.hi << s) | (v.lo >> (64 - s));
+        r.lo = v.lo << s;
+    }
+    return r;
+}
+
+static inline int v_first_one(v128 v) { /* utils.h:168-182: 128 when empty */
+    if (v.lo) return __builtin_ctzll(v.lo);
+    if (v.hi) return 64 + __builtin_ctzll(v.hi);
+    return 128;
+}
+
+static inline int v_first_zero(v128 v) { /* utils.h:187-191 */
+    v128 t = {~v.lo, ~v.hi};
+    return v_first_one(t);
+}
+
+static inline int v_popcount(v128 v) { return __builtin_popcountll(v.lo) + __builtin_popcountll(v.hi); }
+
+static inline int v_pop_between(v128 v, int from, int to) { /* utils.h:263-270 */
+    return v_popcount(v_away0(v_toward0(v, from), from + 128 - to));
+}
+
+static inline v128 v_flip_short_hurdles1(v128 v) { /* utils.h:200-216, threshold 1 */
+    v128 a = v_toward0(v, 1), b = v_away0(v, 1), r;
+    r.lo = v.lo & (a.lo | b.lo);
+    r.hi = v.hi & (a.hi | b.hi);
+    return r;
+}
+
+/* utils.h:576-579 */
+static inline int lane_penalty(int a, int b, int o, int e) { return a == b ? 0 : o + e * (abs(a - b) - 1); }
+
+/* utils.h:587-593 */
+static inline int fwd_col(int l1, int l2) {
+    if (l1 * l2 >= 0) return abs(l1) > abs(l2) ? abs(l1) - abs(l2) : 0;
+    return abs(l1);
+}
+
+/* hurdle_matrix.h:58-68 */
+static inline int lane_destination(int m, int n, int lane) {
+    if (m >= n) {
+        if (lane > 0) return n - lane;
+        if (lane >= n - m) return n;
+        return m + lane;
+    }
+    if (lane < 0) return m + lane;
+    if (lane <= n - m) return m;
+    return n - lane;
+}
+
+/* Bit planes of a 128-byte buffer: bit p of plane0/plane1 = low/high bit of code(buf[p]);
+ * A=00 C=01 G=10 T=11, every other byte 00 (bit_convert.cpp:340-355; bit p <-> char p). */
+static void planes_of(const uint8_t* buf, v128* p0, v128* p1) {
+    uint64_t w0[2] = {0, 0}, w1[2] = {0, 0};
+    for (int p = 0; p < 128; p++) {
+        uint8_t c = buf[p];
+        uint64_t b0 = (c == 'C' || c == 'T'), b1 = (c == 'G' || c == 'T');
+        w0[p >> 6] |= b0 << (p & 63);
+        w1[p >> 6] |= b1 << (p & 63);
+    }
+    p0->lo = w0[0], p0->hi = w0[1];
+    p1->lo = w1[0], p1->hi = w1[1];
+}
+
+/* The in-place byte permutation sse3_convert2bit1 leaves behind (bit_convert.cpp:265-330):
+ * after[q] = before[SRC[q]], SRC[q] = 8*(q mod 16) + P[q div 16]. */
+static const int PERM_P[8] = {0, 2, 1, 3, 4, 6, 5, 7};
+static void convert_permute(uint8_t* buf) {
+    uint8_t t[128];
+    for (int q = 0; q < 128; q++) t[q] = buf[8 * (q & 15) + PERM_P[q >> 4]];
+    memcpy(buf, t, 128);
+}
+
+int orc_greedy_views(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
+                     const uint32_t* ref_off, int mode, uint8_t* views) {
+    uint8_t A[128], B[128]; /* hurdle_matrix.h:136-137; initial content pinned to zero */
+    memset(A, 0, 128);
+    memset(B, 0, 128);
+    for (int64_t i = 0; i < n; i++) {
+        int m = (int)(read_off[i + 1] - read_off[i]), nn = (int)(ref_off[i + 1] - ref_off[i]);
+        if (m > 128) m = 128;
+        if (nn > 128) nn = 128;
+        if (mode == ORC_GREEDY_CLEAN) {
+            memset(A, 0, 128);
+            memset(B, 0, 128);
+        }
+        memcpy(A, reads + read_off[i], m); /* hurdle_matrix.h:630-631 (strncpy without terminator) */
+        memcpy(B, refs + ref_off[i], nn);
+        memcpy(views + i * 256, A, 128);
+        memcpy(views + i * 256 + 128, B, 128);
+        if (mode != ORC_GREEDY_CLEAN) {
+            convert_permute(A);
+            convert_permute(B);
+        }
+    }
+    return 0;
+}
+
+/* per-lane highway cache (hurdle_matrix.h:26-44) */
+typedef struct {
+    int sp, len, sw, hc, nsw, nh, dest;
+} hw_t;
+
+#define ORC_MAX_K 50 /* hurdle_matrix.h:8 */
+
+typedef struct {
+    char* buf;
+    int cap, len;
+} cigar_t;
+
+static void cigar_put(cigar_t* c, int count, char op) {
+    if (!c->buf) return;
+    int w = snprintf(c->buf + c->len, c->cap - c->len, "%d%c", count, op);
+    if (w > 0 && c->len + w < c->cap) c->len += w;
+}
+
+/* hurdle_matrix.h:238-251 */
+static void cigar_update(cigar_t* c, int best_lane, int curr_lane, int total) {
+    if (best_lane < curr_lane)
+        cigar_put(c, curr_lane - best_lane, 'I');
+    else if (best_lane > curr_lane)
+        cigar_put(c, best_lane - curr_lane, 'D');
+    if (total > 0) cigar_put(c, total, 'M');
+}
+
+static int greedy_pair(const uint8_t* Aview, const uint8_t* Bview, int m, int n, int k, int x, int o, int e,
+                       const double sig[3], cigar_t* cg, int* steps_out) {
+    v128 A0, A1, B0, B1;
+    v128 lanes_f[2 * 128 + 1], lanes_o[2 * 128 + 1]; /* index lane+128 (destination lane may be out of band) */
+    hw_t hw[2 * 128 + 1];
+    planes_of(Aview, &A0, &A1);
+    planes_of(Bview, &B0, &B1);
+    int dest_lane = n - m; /* hurdle_matrix.h:649 */
+
+    /* hurdle_matrix.h:441-455 (+ the destination lane when it is out of band: own behaviour, G13) */
+    for (int pass = 0; pass < 2; pass++) {
+        int lo = pass == 0 ? -k : dest_lane, hi = pass == 0 ? k : dest_lane;
+        if (pass == 1 && dest_lane >= -k && dest_lane <= k) break;
+        for (int lane = lo; lane <= hi; lane++) {
+            v128 m0, m1, mk;
+            if (lane < 0) {
+                v128 s0 = v_toward0(A0, -lane), s1 = v_toward0(A1, -lane);
+                m0.lo = s0.lo ^ B0.lo, m0.hi = s0.hi ^ B0.hi;
+                m1.lo = s1.lo ^ B1.lo, m1.hi = s1.hi ^ B1.hi;
+            } else {
+                v128 s0 = v_toward0(B0, lane), s1 = v_toward0(B1, lane);
+                m0.lo = s0.lo ^ A0.lo, m0.hi = s0.hi ^ A0.hi;
+                m1.lo = s1.lo ^ A1.lo, m1.hi = s1.hi ^ A1.hi;
+            }
+            mk.lo = m0.lo | m1.lo, mk.hi = m0.hi | m1.hi;
+            lanes_o[lane + 128] = mk;
+            lanes_f[lane + 128] = v_flip_short_hurdles1(mk);
+            /* hurdle_matrix.h:106-119 */
+            hw[lane + 128].sp = -1;
+            hw[lane + 128].len = 0;
+            hw[lane + 128].sw = hw[lane + 128].hc = hw[lane + 128].nsw = hw[lane + 128].nh = 128;
+            hw[lane + 128].dest = lane_destination(m, n, lane);
+        }
+    }
+
+    int cur_lane = 0, cur_col = 0, cost = 0, first = 1, steps = 0;
+    (void)first; /* GLOBAL: the first-step exemption of hurdle_matrix.h:314 never applies */
+
+    for (;;) {
+        /* ---- _update_highway_list, hurdle_matrix.h:285-362 ---- */
+        int reaching = 0;
+        for (int lane = -k; lane <= k; lane++) {
+            hw_t* h = &hw[lane + 128];
+            int start_col = cur_col + fwd_col(cur_lane, lane);
+            if (h->sp < start_col) {
+                h->nsw = abs(lane - cur_lane);
+                v128 l = v_toward0(lanes_f[lane + 128], start_col);
+                int fz = v_first_zero(l);
+                int nh = v_first_one(v_toward0(l, fz));
+                h->sp = start_col + fz;
+                h->len = nh;
+                if (start_col + fz + nh > h->dest) {
+                    int c = h->dest - (start_col + fz);
+                    h->len = c > 0 ? c : 0;
+                    reaching = 1;
+                }
+            }
+            h->sw = lane_penalty(cur_lane, lane, o, e);
+            h->nh = v_pop_between(lanes_o[lane + 128], start_col, h->sp + h->len);
+            h->hc = x * h->nh;
+        }
+        double best_h = -INFINITY;
+        int best_leap = 0; /* -numeric_limits<int>::infinity() == 0, hurdle_matrix.h:287 */
+        int best = 0;
+        for (int lane = -k; lane <= k; lane++) {
+            hw_t* h = &hw[lane + 128];
+            int cur_cost = -h->sw - h->hc;
+            double heur = sig[0] * h->len + sig[1] * h->nh + sig[2] * h->nsw;
+            int leap = -h->sw;
+            if (reaching) {
+                int fsw = lane_penalty(lane, dest_lane, o, e);
+                heur = cur_cost - fsw - x * (h->dest - h->sp - h->len);
+                leap -= fsw;
+            }
+            if (heur > best_h || (heur == best_h && leap > best_leap)) {
+                best_h = heur;
+                best_leap = leap;
+                best = lane;
+            }
+        }
+        if (hw[best + 128].len <= 0) break; /* hurdle_matrix.h:358-361,408-410 */
+
+        /* ---- _choose_best_highway, hurdle_matrix.h:368-401 ---- */
+        int sp_best = hw[best + 128].sp;
+        int best_cost = hw[best + 128].hc + hw[best + 128].sw;
+        int small_inter = best_cost, small_total = best_cost, chosen = best;
+        for (int lane = -k; lane <= k; lane++) {
+            if (lane == best) continue;
+            hw_t* h = &hw[lane + 128];
+            if (h->sp + fwd_col(lane, best) > sp_best) continue;
+            int endp = h->sp + h->len;
+            int inter = h->sw + v_pop_between(lanes_o[lane + 128], cur_col + fwd_col(cur_lane, lane), endp);
+            int tail = x * v_pop_between(lanes_o[best + 128], fwd_col(lane, best) + endp, sp_best);
+            int total = inter + lane_penalty(lane, best, o, e) + (tail > 0 ? tail : 0);
+            if (total <= small_total && inter <= small_inter) {
+                small_total = total;
+                small_inter = inter;
+                chosen = lane;
+            }
+        }
+
+        /* ---- _step commit, hurdle_matrix.h:411-433 ---- */
+        hw_t* h = &hw[chosen + 128];
+        cost += h->sw + h->hc;
+        int distance = h->sp + h->len - (cur_col + fwd_col(cur_lane, chosen));
+        cigar_update(cg, chosen, cur_lane, distance);
+        cur_lane = chosen;
+        cur_col = h->sp + h->len;
+        steps++;
+        first = 0;
+        if (cur_col >= h->dest) break;
+    }
+
+    /* ---- final hop, hurdle_matrix.h:575-590 ---- */
+    int dest_col = hw[dest_lane + 128].dest;
+    if (cur_lane != dest_lane || cur_col < dest_col) {
+        int sw = lane_penalty(cur_lane, dest_lane, o, e);
+        int distance = v_pop_between(lanes_o[dest_lane + 128], cur_col + fwd_col(cur_lane, dest_lane), dest_col);
+        int hc = x * distance;
+        cost += sw + (hc > 0 ? hc : 0);
+        cigar_update(cg, dest_lane, cur_lane, distance);
+    }
+    if (steps_out) *steps_out = steps;
+    return cost;
+}
+
+int orc_greedy_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
+                     const uint32_t* ref_off, int k, int x, int o, int e, const double* probs, int mode,
+                     int32_t* costs, char* cigars, int cigar_stride, int32_t* steps) {
+    if (k < 0 || k > ORC_MAX_K) return -1;
+    double sig[3]; /* hurdle_matrix.h:536-538 */
+    sig[0] = log(probs[0] / 0.25);
+    sig[1] = log(probs[1] / 0.25);
+    sig[2] = log(probs[2] / 2 / 0.25);
+    uint8_t* views = (uint8_t*)malloc((size_t)n * 256 + 1);
+    if (!views) return -2;
+    orc_greedy_views(n, reads, read_off, refs, ref_off, mode, views);
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (int64_t i = 0; i < n; i++) {
+        int m = (int)(read_off[i + 1] - read_off[i]), nn = (int)(ref_off[i + 1] - ref_off[i]);
+        if (m > 128) m = 128; /* hurdle_matrix.h:626-627 */
+        if (nn > 128) nn = 128;
+        cigar_t cg = {cigars ? cigars + i * cigar_stride : NULL, cigar_stride, 0};
+        if (cg.buf) cg.buf[0] = 0;
+        int st = 0;
+        costs[i] = greedy_pair(views + i * 256, views + i * 256 + 128, m, nn, k, x, o, e, sig, &cg, &st);
+        if (steps) steps[i] = st;
+    }
+    free(views);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * LEAP — LV_BAG.cpp.  Stateless per pair (the persistent tables never leak between pairs).
+ * ------------------------------------------------------------------------------------------------ */
+#define LEAP_AF 200 /* benchmark_utils.h:289 af_threshold */
+
+typedef struct {
+    int lanes;
+    int *start, *end, *ip, *dp; /* [lanes][LEAP_AF+1] */
+} leap_tab;
+
+static int leap_tab_init(leap_tab* t, int k) {
+    t->lanes = 2 * k + 3; /* LV_BAG.cpp:78 */
+    size_t cells = (size_t)t->lanes * (LEAP_AF + 1);
+    t->start = (int*)malloc(cells * sizeof(int) * 4);
+    if (!t->start) return -1;
+    t->end = t->start + cells;
+    t->ip = t->end + cells;
+    t->dp = t->ip + cells;
+    for (size_t i = 0; i < cells * 4; i++) t->start[i] = -2; /* LV_BAG.cpp:95-101 */
+    return 0;
+}
+
+#define T(arr, l, e) (arr)[(size_t)(l) * (LEAP_AF + 1) + (e)]
+
+/* LV_BAG.cpp:9-23 on buffers NUL padded to len (LV_BAG.cpp:110-120) */
+static inline int leap_extend(const char* a, int m, const char* b, int n, int len, int mid, int lane, int pos) {
+    int aoff = lane < mid ? mid - lane : 0, boff = lane > mid ? lane - mid : 0;
+    while (pos < len) {
+        int ia = pos - aoff, ib = pos - boff;
+        char ca = ia < m ? a[ia] : 0, cb = ib < n ? b[ib] : 0;
+        if (ca != cb) break;
+        pos++;
+    }
+    return pos;
+}
+
+static int leap_pair(leap_tab* t, const char* a, int m, const char* b, int n, int k, int x, int o, int ext) {
+    int len = m > n ? m : n; /* benchmark_utils.h:162 */
+    int mid = k + 1, lanes = t->lanes;
+    int used_e = 0, result = -1;
+    T(t->start, mid, 0) = 0; /* LV_BAG.cpp:102-104, ED_GLOBAL */
+    T(t->end, mid, 0) = leap_extend(a, m, b, n, len, mid, mid, 0); /* LV_BAG.cpp:131-147 */
+    if (T(t->end, mid, 0) == len) {
+        result = 0;
+        goto done;
+    }
+    {
+        int converge = 1000000, pass = 0; /* LV_BAG.cpp:122-125 */
+        for (int e = 1; e <= LEAP_AF && !pass; e++) {
+            used_e = e;
+            for (int l = 1; l < lanes - 1; l++) { /* LV_BAG.cpp:151-240 */
+                int top = l >= mid, bot = l <= mid;
+                int en;
+                if (e >= o && (en = T(t->end, l - 1, e - o)) >= 0 && en > T(t->ip, l - 1, e - ext))
+                    T(t->ip, l, e) = en + top;
+                else if (e >= ext && T(t->ip, l - 1, e - ext) >= 0)
+                    T(t->ip, l, e) = T(t->ip, l - 1, e - ext) + top;
+                if (e >= o && (en = T(t->end, l + 1, e - o)) >= 0 && en > T(t->dp, l + 1, e - ext))
+                    T(t->dp, l, e) = en + bot;
+                else if (e >= ext && T(t->dp, l + 1, e - ext) >= 0)
+                    T(t->dp, l, e) = T(t->dp, l + 1, e - ext) + bot;
+                int st = -2;
+                if (e >= x && T(t->end, l, e - x) >= 0) st = T(t->end, l, e - x) + 1;
+                if (T(t->ip, l, e) > st) st = T(t->ip, l, e);
+                if (T(t->dp, l, e) > st) st = T(t->dp, l, e);
+                T(t->start, l, e) = st;
+                if (st >= 0) {
+                    int en2 = leap_extend(a, m, b, n, len, mid, l, st);
+                    T(t->end, l, e) = en2;
+                    if (en2 == len) { /* LV_BAG.cpp:220-238 */
+                        int diff = abs(mid - l);
+                        int conv = e + (diff ? o + (diff - 1) * ext : 0);
+                        if (conv <= LEAP_AF && conv < converge) {
+                            result = e; /* final_ED, NOT converge_ED (LV_BAG.cpp:228,356-358) */
+                            pass = 1;
+                            converge = conv;
+                        }
+                    }
+                }
+            }
+        }
+    }
+done:
+    /* restore the -2 fill for the generations this pair touched */
+    for (int l = 0; l < lanes; l++)
+        for (int e = 0; e <= used_e; e++) T(t->start, l, e) = T(t->end, l, e) = T(t->ip, l, e) = T(t->dp, l, e) = -2;
+    return result;
+}
+
+int orc_leap_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
+                   const uint32_t* ref_off, int k, int x, int o, int e, int32_t* eds) {
+    if (k < 0 || x < 1 || o < 1 || e < 1 || o < e) return -1; /* L4: reference assumes o >= ext; positive penalties */
+    int rc = 0;
+#pragma omp parallel num_threads(g_threads)
+    {
+        leap_tab t;
+        if (leap_tab_init(&t, k) != 0) {
+#pragma omp atomic write
+            rc = -2;
+        } else {
+#pragma omp for schedule(static)
+            for (int64_t i = 0; i < n; i++) {
+                int m = (int)(read_off[i + 1] - read_off[i]), nn = (int)(ref_off[i + 1] - ref_off[i]);
+                eds[i] = leap_pair(&t, reads + read_off[i], m, refs + ref_off[i], nn, k, x, o, e);
+            }
+            free(t.start);
+        }
+    }
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * NW — Gotoh global affine distance (benchmark_utils.h:139-142,288).
+ * ------------------------------------------------------------------------------------------------ */
+#define NW_INF (1 << 28)
+
+static int nw_pair(const char* a, int m, const char* b, int n, int x, int o, int e, int* H, int* F) {
+    /* row-wise; H[j], F[j] (vertical gap state per column), E carried along the row */
+    H[0] = 0;
+    F[0] = NW_INF;
+    for (int j = 1; j <= n; j++) {
+        H[j] = o + (j - 1) * e;
+        F[j] = NW_INF;
+    }
+    for (int i = 1; i <= m; i++) {
+        int diag = H[0];
+        H[0] = o + (i - 1) * e;
+        int E = NW_INF;
+        char ca = a[i - 1];
+        for (int j = 1; j <= n; j++) {
+            int up = H[j];
+            int f = F[j] + e < up + o ? F[j] + e : up + o;
+            int ee = E + e < H[j - 1] + o ? E + e : H[j - 1] + o;
+            int d = diag + (ca != b[j - 1] ? x : 0);
+            int h = d < f ? d : f;
+            if (ee < h) h = ee;
+            diag = up;
+            H[j] = h;
+            F[j] = f;
+            E = ee;
+        }
+    }
+    return H[n];
+}
+
+int orc_nw_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
+                 const uint32_t* ref_off, int x, int o, int e, int32_t* penalties) {
+#pragma omp parallel num_threads(g_threads)
+    {
+        int cap = 0;
+        int* buf = NULL;
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < n; i++) {
+            int m = (int)(read_off[i + 1] - read_off[i]), nn = (int)(ref_off[i + 1] - ref_off[i]);
+            if (nn + 1 > cap) {
+                cap = nn + 64;
+                free(buf);
+                buf = (int*)malloc(sizeof(int) * 2 * cap);
+            }
+            penalties[i] = nw_pair(reads + read_off[i], m, refs + ref_off[i], nn, x, o, e, buf, buf + cap);
+        }
+        free(buf);
+    }
+    return 0;
+}
+
+int orc_levenshtein_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
+                          const uint32_t* ref_off, int32_t* dist) {
+#pragma omp parallel num_threads(g_threads)
+    {
+        int cap = 0;
+        int* row = NULL;
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < n; i++) {
+            const char *a = reads + read_off[i], *b = refs + ref_off[i];
+            int m = (int)(read_off[i + 1] - read_off[i]), nn = (int)(ref_off[i + 1] - ref_off[i]);
+            if (nn + 1 > cap) {
+                cap = nn + 64;
+                free(row);
+                row = (int*)malloc(sizeof(int) * cap);
+            }
+            for (int j = 0; j <= nn; j++) row[j] = j;
+            for (int r = 1; r <= m; r++) {
+                int diag = row[0];
+                row[0] = r;
+                for (int j = 1; j <= nn; j++) {
+                    int up = row[j];
+                    int best = diag + (a[r - 1] != b[j - 1]);
+                    if (up + 1 < best) best = up + 1;
+                    if (row[j - 1] + 1 < best) best = row[j - 1] + 1;
+                    diag = up;
+                    row[j] = best;
+                }
+            }
+            dist[i] = row[nn];
+        }
+        free(row);
+    }
+    return 0;
+}
+
+/* Full-matrix Gotoh with traceback.  State order when several predecessors tie, walking back from (m,n):
+ * in H prefer the diagonal, then E ('D': consumes ref), then F ('I': consumes read); inside a gap prefer
+ * extending it.  Own convention — parasail's is internal. */
+int orc_nw_cigar_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
+                       const uint32_t* ref_off, int x, int o, int e, int32_t* penalties, char* cigars,
+                       int cigar_stride) {
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (int64_t p = 0; p < n; p++) {
+        const char *a = reads + read_off[p], *b = refs + ref_off[p];
+        int m = (int)(read_off[p + 1] - read_off[p]), nn = (int)(ref_off[p + 1] - ref_off[p]);
+        size_t W = (size_t)nn + 1, cells = ((size_t)m + 1) * W;
+        int* H = (int*)malloc(sizeof(int) * cells * 3);
+        int *E = H + cells, *F = E + cells;
+        char* ops = (char*)malloc((size_t)m + nn + 2);
+        H[0] = 0;
+        E[0] = F[0] = NW_INF;
+        for (int j = 1; j <= nn; j++) {
+            E[j] = o + (j - 1) * e;
+            H[j] = E[j];
+            F[j] = NW_INF;
+        }
+        for (int i = 1; i <= m; i++) {
+            F[i * W] = o + (i - 1) * e;
+            H[i * W] = F[i * W];
+            E[i * W] = NW_INF;
+            for (int j = 1; j <= nn; j++) {
+                size_t c = i * W + j;
+                int ee = E[c - 1] + e < H[c - 1] + o ? E[c - 1] + e : H[c - 1] + o;
+                int ff = F[c - W] + e < H[c - W] + o ? F[c - W] + e : H[c - W] + o;
+                int d = H[c - W - 1] + (a[i - 1] != b[j - 1] ? x : 0);
+                int h = d;
+                if (ee < h) h = ee;
+                if (ff < h) h = ff;
+                H[c] = h, E[c] = ee, F[c] = ff;
+            }
+        }
+        penalties[p] = H[(size_t)m * W + nn];
+        if (cigars) {
+            int i = m, j = nn, cnt = 0, state = 0; /* 0=H 1=E 2=F */
+            while (i > 0 || j > 0) {
+                size_t c = i * W + j;
+                if (state == 0) {
+                    if (i > 0 && j > 0 && H[c] == H[c - W - 1] + (a[i - 1] != b[j - 1] ? x : 0)) {
+                        ops[cnt++] = a[i - 1] != b[j - 1] ? 'X' : '=';
+                        i--, j--;
+                    } else if (j > 0 && H[c] == E[c])
+                        state = 1;
+                    else
+                        state = 2;
+                } else if (state == 1) {
+                    ops[cnt++] = 'D';
+                    if (!(j > 1 && E[c] == E[c - 1] + e)) state = 0;
+                    j--;
+                } else {
+                    ops[cnt++] = 'I';
+                    if (!(i > 1 && F[c] == F[c - W] + e)) state = 0;
+                    i--;
+                }
+            }
+            char* out = cigars + p * cigar_stride;
+            int len = 0;
+            out[0] = 0;
+            for (int q = cnt - 1; q >= 0;) {
+                int r = q;
+                while (r >= 0 && ops[r] == ops[q]) r--;
+                int w = snprintf(out + len, cigar_stride - len, "%d%c", q - r, ops[q]);
+                if (w > 0 && len + w < cigar_stride) len += w;
+                q = r;
+            }
+        }
+        free(ops);
+        free(H);
+    }
+    return 0;
+}
+
+/* benchmark_coverage.h:26-67 */
+static int lcm_string(const char* s1, int m, const char* cigar, int threshold, char* out) {
+    int len = 0, i1 = 0;
+    const char* p = cigar;
+    while (*p) {
+        int cnt = 0, have = 0;
+        while (*p >= '0' && *p <= '9') {
+            cnt = cnt * 10 + (*p - '0');
+            p++;
+            have = 1;
+        }
+        if (!have || !*p) break;
+        char op = *p++;
+        if (op == 'X' || op == 'I') {
+            i1 += cnt;
+        } else if (op == '=' || op == 'M') {
+            for (int i = 0; i < cnt; i++) {
+                if (cnt >= threshold && i1 < m) out[len++] = s1[i1];
+                i1++;
+            }
+        } /* 'D' only advances the ref index, which the LCM never reads */
+    }
+    return len;
+}
+
+/* benchmark_coverage.h:73-91: s2 is a subsequence of s1 */
+static int covers_str(const char* s1, int n1, const char* s2, int n2) {
+    if (n1 < n2) return 0;
+    int i = 0;
+    for (int j = 0; j < n2; j++) {
+        if (i >= n1) return 0;
+        while (s1[i] != s2[j]) {
+            i++;
+            if (i >= n1) return 0;
+        }
+        i++;
+    }
+    return 1;
+}
+
+int orc_coverage_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
+                       const uint32_t* ref_off, const char* cigars1, int stride1, int thr1,
+                       const char* cigars2, int stride2, int thr2, uint8_t* out) {
+    (void)refs;
+    (void)ref_off;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (int64_t i = 0; i < n; i++) {
+        int m = (int)(read_off[i + 1] - read_off[i]);
+        char* l1 = (char*)malloc(2 * (size_t)m + 2);
+        char* l2 = l1 + m + 1;
+        int n1 = lcm_string(reads + read_off[i], m, cigars1 + i * stride1, thr1, l1);
+        int n2 = lcm_string(reads + read_off[i], m, cigars2 + i * stride2, thr2, l2);
+        out[i] = (uint8_t)covers_str(l1, n1, l2, n2);
+        free(l1);
+    }
+    return 0;
+}

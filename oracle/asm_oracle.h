@@ -1,0 +1,80 @@
+/* TEST INFRASTRUCTURE ONLY — the oracle.
+ *
+ * A plain-C CPU restatement of the three aligners on the reference's benchmark hot path, written from the
+ * behavioural specification and the reference sources read as text.  It exists so that the
+ * HIP kernels can be checked on machines where /root/reference does not exist (the GPU box).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the product library never does.
+ *
+ * Pinning: tests/test_oracle_vs_reference.py diffs every function here against oracle/_ref/libasm_ref.so
+ * (the real reference compiled in place, this container only) and tests/golden/ holds vectors generated
+ * from that library by tests/golden/make_golden.py.  NW has no reference-side pin (parasail is absent
+ * from the reference tree): its parity is by definition (Gotoh global affine distance),
+ * cross-checked against plain Levenshtein DP for unit costs.
+ *
+ * Batch layout used by every entry point: `reads`/`refs` are concatenated ASCII strings (no terminators),
+ * `*_off` are n+1 prefix offsets (uint32), pair i is reads[read_off[i] .. read_off[i+1]).
+ */
+#ifndef ASM_ORACLE_H
+#define ASM_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_GREEDY_SEQUENTIAL 0 /* reference as run: stale buffer tails flow from pair to pair (F4)     */
+#define ORC_GREEDY_CLEAN 1      /* buffers zeroed before every pair: order independent                   */
+
+/* Greedy hurdle-matrix aligner, GLOBAL mode.
+ * Follows GASMA/hurdle_matrix.h:285-455,568-597,625-665 and GASMA/utils.h:131-153,168-216,263-270,576-593.
+ * probs = {p_match, p_mismatch, p_indel} (hurdle_matrix.h:552-559 defaults 0.80, 0.20/3, 0.40/3).
+ * cigars may be NULL; otherwise n*cigar_stride bytes, NUL terminated.
+ * steps (optional): number of _step() commits per pair (work statistic).
+ * Pairs whose destination lane n-m lies outside [-k,k] are undefined in the reference; here the
+ * destination lane is built like an in-band lane (documented own behaviour, excluded from parity counts). */
+int orc_greedy_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
+                     const uint32_t* ref_off, int k, int x, int o, int e, const double* probs, int mode,
+                     int32_t* costs, char* cigars, int cigar_stride, int32_t* steps);
+
+/* The 128-byte A and B buffers each pair's conversion sees (A at views[i*256], B at views[i*256+128]).
+ * Model of the in-place permutation of GASMA/bit_convert.cpp:265-330 (SRC table). */
+int orc_greedy_views(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
+                     const uint32_t* ref_off, int mode, uint8_t* views);
+
+/* LEAP (banded affine Landau-Vishkin "BAG") penalty = final_ED, as benchmarked.
+ * Follows GASMA/benchmark/LEAP_SIMD/LV_BAG.cpp:9-23,65-245,356-358 with init(k,200,ED_GLOBAL,x,o,e).
+ * eds[i] = -1 when no lane passes within af_threshold=200 (reference returns a stale value there). */
+int orc_leap_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
+                   const uint32_t* ref_off, int k, int x, int o, int e, int32_t* eds);
+
+/* NW: global affine-gap distance, match 0, mismatch x, gap(L) = o + (L-1)*e.
+ * Semantics of the call site GASMA/benchmark/benchmark_utils.h:139-142,288 (parasail, absent): penalty = -score. */
+int orc_nw_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
+                 const uint32_t* ref_off, int x, int o, int e, int32_t* penalties);
+
+/* Plain Levenshtein distance (independent cross-check for x=o=e=1). */
+int orc_levenshtein_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
+                          const uint32_t* ref_off, int32_t* dist);
+
+/* NW with traceback: CIGAR with '=', 'X', 'I', 'D' (own documented tie-break: diagonal, then I, then D
+ * when walking back from (m,n)); parasail's preference is internal and unpinned. */
+int orc_nw_cigar_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
+                       const uint32_t* ref_off, int x, int o, int e, int32_t* penalties, char* cigars,
+                       int cigar_stride);
+
+/* Coverage metric: long_consecutive_matching_substring + covers
+ * (GASMA/benchmark/benchmark_coverage.h:26-67,73-91; call site benchmark_utils.h:214-225,256).
+ * out[i] = 1 when LCM(read,ref,cigar1,thr1) covers LCM(read,ref,cigar2,thr2). */
+int orc_coverage_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
+                       const uint32_t* ref_off, const char* cigars1, int stride1, int thr1,
+                       const char* cigars2, int stride2, int thr2, uint8_t* out);
+
+/* number of OpenMP threads the batch entry points will use (LEAP/NW/Greedy-clean are parallel over pairs;
+ * Greedy-sequential resolves views serially first, then runs pairs in parallel). */
+int orc_set_threads(int nthreads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
