@@ -1,0 +1,150 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the oracle on the same seeded inputs.
+Bar: bit-exact int32 penalties.  Sizes are what the oracle finishes in seconds."""
+import numpy as np
+import pytest
+
+from tests.util import KNOWN_PAIRS, random_ragged_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(name, got, want, hb):
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, (f"{name}: {bad.size}/{hb.n} differ; first {bad[:5]} got {got[bad[:5]]} want {want[bad[:5]]} "
+                           f"pair {hb.pair(int(bad[0]))}")
+
+
+@pytest.mark.parametrize("cfgname,n", [("C1", 10000), ("C2", 20000), ("C4", 20000)])
+def test_three_aligners_narrow_band(asm, engine, oracle, cfgname, n):
+    """BASELINE configs with k=3, x=o=e=1: thread-per-pair kernels."""
+    cfg, _, params = asm.workload(cfgname)
+    hb = asm.generate_pairs(cfg, 0, n)
+    batch = engine.upload(hb, asm.GREEDY_CLEAN)
+    _check("nw", engine.align(batch, asm.NW, params), oracle.nw(hb), hb)
+    _check("leap", engine.align(batch, asm.LEAP, params), oracle.leap(hb, k=params.k), hb)
+    _check("greedy", engine.align(batch, asm.GREEDY, params), oracle.greedy(hb, k=params.k, mode=1), hb)
+
+
+def test_sequential_mode_matches_reference_order_dependence(asm, engine, oracle):
+    """Greedy 'sequential' mode = the reference as run (stale buffer tails)."""
+    cfg, _, params = asm.workload("C2")
+    hb = asm.generate_pairs(cfg, 0, 20000)
+    batch = engine.upload(hb, asm.GREEDY_SEQUENTIAL)
+    want = oracle.greedy(hb, k=3, mode=0)
+    _check("greedy-seq", engine.align(batch, asm.GREEDY, params), want, hb)
+    assert (want != oracle.greedy(hb, k=3, mode=1)).sum() > 0  # the two modes really differ on this input
+    # LEAP / NW ignore the tail bits
+    _check("leap", engine.align(batch, asm.LEAP, params), oracle.leap(hb, k=3), hb)
+    _check("nw", engine.align(batch, asm.NW, params), oracle.nw(hb), hb)
+
+
+def test_c3_wide_band_150bp(asm, engine, oracle):
+    """C3: 150 bp, err .20, k=30 — workgroup-per-pair kernels; Greedy sees the first 128 bases (F6)."""
+    cfg, _, params = asm.workload("C3")
+    hb = asm.generate_pairs(cfg, 0, 4000)
+    for mode in (asm.GREEDY_CLEAN, asm.GREEDY_SEQUENTIAL):
+        batch = engine.upload(hb, mode)
+        _check("greedy", engine.align(batch, asm.GREEDY, params), oracle.greedy(hb, k=30, mode=mode), hb)
+    _check("leap", engine.align(batch, asm.LEAP, params), oracle.leap(hb, k=30), hb)
+    _check("nw", engine.align(batch, asm.NW, params), oracle.nw(hb), hb)
+
+
+def test_c5_mixed_lengths(asm, engine, oracle):
+    """C5: 64-300 bp in one batch (three 128-bit granules per plane)."""
+    cfg, _, params = asm.workload("C5")
+    hb = asm.generate_pairs(cfg, 0, 6000)
+    batch = engine.upload(hb, asm.GREEDY_CLEAN)
+    _check("nw", engine.align(batch, asm.NW, params), oracle.nw(hb), hb)
+    _check("leap", engine.align(batch, asm.LEAP, params), oracle.leap(hb, k=3), hb)
+    _check("greedy", engine.align(batch, asm.GREEDY, params), oracle.greedy(hb, k=3, mode=1), hb)
+
+
+@pytest.mark.parametrize("k", [0, 1, 2, 4, 5, 6, 10, 50])
+def test_band_widths(asm, engine, oracle, k):
+    cfg, _, _ = asm.workload("C2")
+    hb = asm.generate_pairs(cfg, 7, 3000)
+    params = asm.Params.default(k=k)
+    batch = engine.upload(hb, asm.GREEDY_CLEAN)
+    _check(f"greedy k={k}", engine.align(batch, asm.GREEDY, params), oracle.greedy(hb, k=k, mode=1), hb)
+    _check(f"leap k={k}", engine.align(batch, asm.LEAP, params), oracle.leap(hb, k=k), hb)
+
+
+@pytest.mark.parametrize("k,x,o,e", [(3, 2, 3, 1), (5, 4, 6, 2), (10, 1, 2, 1), (3, 1, 1, 1), (3, 3, 5, 5), (2, 15, 15, 1)])
+def test_general_penalties(asm, engine, oracle, k, x, o, e):
+    """Arbitrary (x, o, e): affine NW, generic LEAP, Greedy costs."""
+    cfg, _, _ = asm.workload("C2")
+    hb = asm.generate_pairs(cfg, 11, 3000)
+    params = asm.Params.default(k=k, x=x, o=o, e=e)
+    batch = engine.upload(hb, asm.GREEDY_CLEAN)
+    _check("nw", engine.align(batch, asm.NW, params), oracle.nw(hb, x, o, e), hb)
+    _check("leap", engine.align(batch, asm.LEAP, params), oracle.leap(hb, k, x, o, e), hb)
+    _check("greedy", engine.align(batch, asm.GREEDY, params), oracle.greedy(hb, k, x, o, e, mode=1), hb)
+
+
+@pytest.mark.parametrize("x,o,e", [(1, 1, 1), (2, 3, 1)])
+def test_ragged_and_edge_lengths(asm, engine, oracle, x, o, e):
+    """Empty strings, 1, 63/64/65, 127/128/129, 255/256/257, 300 and random lengths in one batch."""
+    hb = random_ragged_batch(asm, 5, 1500, 0, 300)
+    params = asm.Params.default(k=3, x=x, o=o, e=e)
+    batch = engine.upload(hb, asm.GREEDY_CLEAN)
+    _check("nw", engine.align(batch, asm.NW, params), oracle.nw(hb, x, o, e), hb)
+    _check("leap", engine.align(batch, asm.LEAP, params), oracle.leap(hb, 3, x, o, e), hb)
+    _check("greedy", engine.align(batch, asm.GREEDY, params), oracle.greedy(hb, 3, x, o, e, mode=1), hb)
+    _check("greedy k=12", engine.align(batch, asm.GREEDY, asm.Params.default(k=12, x=x, o=o, e=e)),
+           oracle.greedy(hb, 12, x, o, e, mode=1), hb)
+    _check("leap k=12", engine.align(batch, asm.LEAP, asm.Params.default(k=12, x=x, o=o, e=e)),
+           oracle.leap(hb, 12, x, o, e), hb)
+
+
+def test_long_sequences_512(asm, engine, oracle):
+    hb = random_ragged_batch(asm, 9, 400, 300, 512, err=0.05)
+    params = asm.Params.default(k=3)
+    batch = engine.upload(hb, asm.GREEDY_CLEAN)
+    _check("nw", engine.align(batch, asm.NW, params), oracle.nw(hb), hb)
+    _check("nw affine", engine.align(batch, asm.NW, asm.Params.default(x=2, o=3, e=1)), oracle.nw(hb, 2, 3, 1), hb)
+    _check("leap", engine.align(batch, asm.LEAP, params), oracle.leap(hb, k=3), hb)
+    _check("greedy", engine.align(batch, asm.GREEDY, params), oracle.greedy(hb, k=3, mode=1), hb)
+
+
+def test_known_answer_vectors(asm, engine):
+    """The reference's literal pairs, values produced by the compiled reference."""
+    hb = asm.HostBatch.from_strings([KNOWN_PAIRS[k] for k in ("KA-0", "KA-5", "KA-6")])
+    p = asm.Params.default(k=3)
+    assert engine.align_host(hb, asm.GREEDY, p, asm.GREEDY_CLEAN).tolist() == [6, 3, 0]
+    assert engine.align_host(hb, asm.LEAP, p).tolist() == [5, 2, 0]      # KA-5: LEAP 2 < NW 3 (F5)
+    assert engine.align_host(hb, asm.NW, p).tolist() == [5, 3, 0]
+
+
+def test_empty_batch_and_errors(asm, engine):
+    hb = asm.HostBatch.from_strings([])
+    assert engine.align_host(hb, asm.NW, asm.Params.default()).shape == (0,)
+    with pytest.raises(asm.AsmError):
+        engine.align_host(asm.HostBatch.from_strings([("ACGT", "ACGT")]), asm.GREEDY, asm.Params.default(k=51))
+    with pytest.raises(asm.AsmError):
+        engine.align_host(asm.HostBatch.from_strings([("ACGT", "ACGT")]), asm.LEAP, asm.Params.default(o=1, e=2))
+    with pytest.raises(asm.AsmError):
+        engine.align_host(asm.HostBatch.from_strings([("A" * 513, "ACGT")]), asm.NW, asm.Params.default())
+
+
+def test_device_generator_matches_host_generator(asm, engine):
+    for name, n in (("C2", 5000), ("C4", 5000), ("C5", 3000), ("C3", 2000)):
+        cfg, _, _ = asm.workload(name)
+        hb = asm.generate_pairs(cfg, 123, n)
+        db = engine.generate(cfg, 123, n).download()
+        assert np.array_equal(hb.read_off, db.read_off) and np.array_equal(hb.ref_off, db.ref_off), name
+        assert np.array_equal(hb.reads, db.reads) and np.array_equal(hb.refs, db.refs), name
+
+
+def test_count_equal(asm, engine, oracle):
+    cfg, _, params = asm.workload("C2")
+    hb = asm.generate_pairs(cfg, 0, 10000)
+    batch = engine.upload(hb)
+    d_nw, d_leap, d_cnt = engine.malloc(4 * hb.n), engine.malloc(4 * hb.n), engine.malloc(8)
+    engine.align_async(batch, asm.NW, params, d_nw)
+    engine.align_async(batch, asm.LEAP, params, d_leap)
+    engine.memset_async(d_cnt, 0, 8)
+    engine.count_equal_async(d_nw, d_leap, hb.n, d_cnt)
+    cnt = int(engine.to_host(d_cnt, 1, np.uint64)[0])
+    assert cnt == int((oracle.nw(hb) == oracle.leap(hb, k=3)).sum())
+    for p in (d_nw, d_leap, d_cnt):
+        engine.free(p)
