@@ -121,6 +121,8 @@ def load_library() -> ctypes.CDLL:
         "asm_align_batch_async": (i32, [vp, vp, i32, c.POINTER(Params), vp]),
         "asm_align_batch": (i32, [vp, i32, i64, vp, vp, vp, vp, c.POINTER(Params), i32, vp]),
         "asm_count_equal_async": (i32, [vp, vp, vp, i64, vp]),
+        "asm_accuracy_async": (i32, [vp, vp, vp, vp, vp, i64, vp]),
+        "asm_run_benchmark_async": (i32, [vp, vp, c.POINTER(Params), i32, vp, vp, vp, vp, vp]),
         "asm_device_malloc": (i32, [vp, c.c_size_t, c.POINTER(vp)]),
         "asm_device_free": (i32, [vp, vp]),
         "asm_memcpy_d2h": (i32, [vp, vp, vp, c.c_size_t]),
@@ -349,6 +351,18 @@ class Engine:
 
     def count_equal_async(self, d_a: int, d_b: int, n: int, d_count: int) -> None:
         self._chk(self.lib.asm_count_equal_async(self.h, d_a, d_b, n, d_count))
+
+    def accuracy_async(self, d_nw: int, d_leap: Optional[int], d_greedy: Optional[int], n: int, d_counters: int,
+                       d_answers: Optional[int] = None) -> None:
+        """counters (uint64[4]) += {total, nw_ok, leap_ok, greedy_ok} — benchmark_utils.h:249-255."""
+        self._chk(self.lib.asm_accuracy_async(self.h, d_nw, d_leap, d_greedy, d_answers, n, d_counters))
+
+    def run_benchmark_async(self, batch: DeviceBatch, params: Params, d_nw: Optional[int], d_leap: Optional[int],
+                            d_greedy: Optional[int], d_counters: Optional[int], repack: bool = True,
+                            d_answers: Optional[int] = None) -> None:
+        """`_run_benchmark` over the whole resident batch (pack, NW, LEAP, Greedy, counters) in one call."""
+        self._chk(self.lib.asm_run_benchmark_async(self.h, batch.ptr, ctypes.byref(params), 1 if repack else 0, d_nw,
+                                                   d_leap, d_greedy, d_answers, d_counters))
 
     # ---- timing ----
     def timer(self) -> "Timer":

@@ -501,10 +501,36 @@ int asm_count_equal_async(asm_handle* h, const int32_t* d_a, const int32_t* d_b,
     if (n <= 0) return ASM_OK;
     HIPCHK(h, hipSetDevice(h->device));
     int64_t blocks = (n + ASM_BLOCK - 1) / ASM_BLOCK;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 512) blocks = 512;
     hipLaunchKernelGGL(count_equal_kernel, dim3((unsigned)blocks), dim3(ASM_BLOCK), 0, h->stream, d_a, d_b, (long)n, d_count);
     HIPCHK(h, hipGetLastError());
     return ASM_OK;
+}
+
+int asm_accuracy_async(asm_handle* h, const int32_t* d_nw, const int32_t* d_leap, const int32_t* d_greedy,
+                       const int32_t* d_answers, int64_t n, unsigned long long* d_counters) {
+    if (!h || !d_nw || !d_counters) return fail(h, ASM_EINVAL, "asm_accuracy_async: NULL argument");
+    if (n <= 0) return ASM_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    int64_t blocks = (n + ASM_BLOCK - 1) / ASM_BLOCK;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(accuracy_kernel, dim3((unsigned)blocks), dim3(ASM_BLOCK), 0, h->stream, d_nw, d_leap, d_greedy,
+                       d_answers, (long)n, d_counters);
+    HIPCHK(h, hipGetLastError());
+    return ASM_OK;
+}
+
+int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, int repack, int32_t* d_nw,
+                            int32_t* d_leap, int32_t* d_greedy, const int32_t* d_answers,
+                            unsigned long long* d_counters) {
+    if (!h || !b || !p) return fail(h, ASM_EINVAL, "asm_run_benchmark_async: NULL argument");
+    int rc = ASM_OK;
+    if (repack) rc = asm_batch_pack_async(h, b);
+    if (!rc && d_nw) rc = asm_align_batch_async(h, b, ASM_NW, p, d_nw);
+    if (!rc && d_leap) rc = asm_align_batch_async(h, b, ASM_LEAP, p, d_leap);
+    if (!rc && d_greedy) rc = asm_align_batch_async(h, b, ASM_GREEDY, p, d_greedy);
+    if (!rc && d_counters && d_nw) rc = asm_accuracy_async(h, d_nw, d_leap, d_greedy, d_answers, b->n, d_counters);
+    return rc;
 }
 
 /* ---------------------------------------------------------------------------------------------------- */

@@ -467,17 +467,58 @@ __global__ __launch_bounds__(ASM_BLOCK) void nw_unit_kernel(const uint4* __restr
     out[i] = score;
 }
 
-// accuracy counter (benchmark_utils.h:253-255)
+// accuracy counters (benchmark_utils.h:249-255).  A single hot word saturates at ~88 atomics/us on this chip
+// (MI355X_MICROARCH.md "dequeue"), so: wave shuffle -> LDS -> ONE atomic per workgroup, and a small grid.
+ASM_DEV unsigned int block_sum_256(unsigned int v, unsigned int* s_part /* [4] */) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    unsigned int r = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    __syncthreads();
+    return r;
+}
+
 __global__ __launch_bounds__(ASM_BLOCK) void count_equal_kernel(const int32_t* __restrict__ a,
                                                                 const int32_t* __restrict__ b, long n,
                                                                 unsigned long long* __restrict__ count) {
+    __shared__ unsigned int s_part[4];
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
     unsigned int local = 0;
     for (; i < n; i += stride) local += (a[i] == b[i]) ? 1u : 0u;
-    // wave reduction, then one atomic per wave
-    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(count, (unsigned long long)local);
+    const unsigned int tot = block_sum_256(local, s_part);
+    if (threadIdx.x == 0 && tot) atomicAdd(count, (unsigned long long)tot);
+}
+
+// All of `_run_benchmark`'s counters in one pass: counters = {total_tests, nw_correct, LEAP_correct,
+// greedy_correct}; the correct answer is answers[i] when given and != INT32_MIN, else the NW penalty
+// (benchmark_utils.h:249-252).  leap / greedy may be null (aligner not run).
+__global__ __launch_bounds__(ASM_BLOCK) void accuracy_kernel(const int32_t* __restrict__ nw,
+                                                             const int32_t* __restrict__ leap,
+                                                             const int32_t* __restrict__ greedy,
+                                                             const int32_t* __restrict__ answers, long n,
+                                                             unsigned long long* __restrict__ counters) {
+    __shared__ unsigned int s_part[4];
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    unsigned int c_nw = 0, c_leap = 0, c_greedy = 0;
+    for (; i < n; i += stride) {
+        const int32_t p = nw[i];
+        int32_t want = p;
+        if (answers != nullptr && answers[i] != INT32_MIN) want = answers[i];
+        c_nw += (p == want) ? 1u : 0u;
+        if (leap != nullptr) c_leap += (leap[i] == want) ? 1u : 0u;
+        if (greedy != nullptr) c_greedy += (greedy[i] == want) ? 1u : 0u;
+    }
+    const unsigned int t_nw = block_sum_256(c_nw, s_part);
+    const unsigned int t_leap = block_sum_256(c_leap, s_part);
+    const unsigned int t_greedy = block_sum_256(c_greedy, s_part);
+    if (threadIdx.x == 0) {
+        if (blockIdx.x == 0) atomicAdd(&counters[0], (unsigned long long)n);
+        if (t_nw) atomicAdd(&counters[1], (unsigned long long)t_nw);
+        if (t_leap) atomicAdd(&counters[2], (unsigned long long)t_leap);
+        if (t_greedy) atomicAdd(&counters[3], (unsigned long long)t_greedy);
+    }
 }
 
 // --------------------------------------------------------------------------------------------------------

@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py — the hot path on N GPUs of one node: `python bench.py --gpus N --steps K --warmup W`.
+
+A *step* is one pass of the reference's per-pair benchmark work (`benchmark::_run_benchmark`,
+GASMA/benchmark/benchmark_utils.h:231-259) over one resident batch: pack (ASCII -> bit planes, the reference
+converts inside its timed Greedy call), NW, LEAP, Greedy, and the three accuracy counters.  The batch is
+BASELINE.json's configs[1] ("C2": 1e6 simulated 100 bp pairs, err 0.10, k=3, x=o=e=1) per GPU, generated on the
+device from the seeded stream (rank r owns pairs [r*n, (r+1)*n)) — inputs are resident in HBM before the timed
+region.  Pairs are independent, so ranks share nothing on the data path (weak scaling); one RCCL all-reduce of the
+four int64 counters {total, nw_ok, leap_ok, greedy_ok} closes the timed region.
+
+Prints ONE JSON line on rank 0 (see the contract in the task statement) with `roofline` for the dominant kernel and
+`cpu_baseline` (the oracle = CPU port of the reference, timed on this host's cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md §Chip-level parameters)
+
+
+def algorithmic_bytes(m, n, aligners=1):
+    """2-bit packed inputs read once + one int32 penalty per aligner, per pair."""
+    return (np.ceil(2 * m / 8) + np.ceil(2 * n / 8) + 4 * aligners).sum()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="C2")
+    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the workload's batch, capped 1e6)")
+    ap.add_argument("--cpu-sample", type=int, default=300_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    import approximate_string_matching_amd as asm
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg, n_default, params = asm.workload(args.workload)
+    n = args.pairs or min(n_default, 1_000_000)
+    eng = asm.Engine(local_rank)
+    # everything (kernels, counters, the all-reduce) is ordered on torch's current stream
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    batch = eng.generate(cfg, rank * n, n)  # this rank's shard of the seeded stream, straight into HBM
+    aligners = [asm.NW, asm.LEAP, asm.GREEDY] if args.workload != "C3" else [asm.LEAP, asm.GREEDY]
+    d_pen = {a: eng.malloc(4 * n) for a in aligners}
+    counters = torch.zeros(4, dtype=torch.int64, device="cuda")  # total, nw_ok, leap_ok, greedy_ok
+    d_cnt = counters.data_ptr()
+
+    d_nw, d_leap, d_greedy = d_pen.get(asm.NW), d_pen.get(asm.LEAP), d_pen.get(asm.GREEDY)
+
+    def step(timers=None):
+        if timers is None:
+            # `_run_benchmark` for the whole batch: pack, aligners, counters — one C-ABI call, five launches
+            eng.run_benchmark_async(batch, params, d_nw, d_leap, d_greedy, d_cnt, repack=True)
+            return
+        seq = [("pack", lambda: eng.pack_async(batch))]
+        for a in aligners:
+            seq.append((asm.ALIGNER_NAMES[a], lambda a=a: eng.align_async(batch, a, params, d_pen[a])))
+        for name, fn in seq:
+            t = eng.timer()
+            t.start()
+            fn()
+            t.stop()
+            timers.setdefault(name, []).append(t)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    counters.zero_()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if dist is not None:
+        dist.all_reduce(counters)  # the only collective: 32 bytes over xGMI
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    cnt = counters.cpu().numpy().copy()
+    # per-kernel durations: a second, separately instrumented pass (HIP events on the engine's stream around every
+    # launch) so the event records do not sit inside the whole-job timing above
+    timers = {}
+    for _ in range(min(args.steps, 20)):
+        step(timers)
+    eng.synchronize()
+    kernel_ms = {k: float(np.mean([t.elapsed_ms() for t in v])) for k, v in timers.items()}
+
+    if rank == 0:
+        total_pairs = world * n * args.steps
+        value = total_pairs / elapsed
+        hb = batch.download()
+        m_len, n_len = hb.lengths()
+        dom = max(kernel_ms, key=kernel_ms.get)
+        if dom == "pack":
+            alg_bytes = float((m_len + n_len).sum() + 68 * n)  # ASCII in, planes + lengths out
+        else:
+            alg_bytes = float(algorithmic_bytes(m_len, n_len, 1))
+        achieved = alg_bytes / (kernel_ms[dom] * 1e-3) / 1e9
+        out = {
+            "metric": "alignments/sec (1e6-pair batch, 100bp, err=0.10) per GPU; NW penalty bit-exact %",
+            "value": value,
+            "unit": "read pairs/s through NW+LEAP+Greedy (whole job)",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: {n} pairs per GPU, len {cfg.len_lo}-{cfg.len_hi}, err {cfg.err:.2f}, "
+                            f"k={params.k}, x=o=e={params.x},{params.o},{params.e}, aligners "
+                            + "+".join(asm.ALIGNER_NAMES[a] for a in aligners) + ", greedy tails=clean",
+                "pairs_per_gpu": n,
+                "sharding": "independent pairs, contiguous shard per rank, one 32-byte all-reduce of counters",
+            },
+            "kernel_ms": kernel_ms,
+            "kernel_pairs_per_s": {k: n / (v * 1e-3) for k, v in kernel_ms.items()},
+            "leap_greedy_pairs_per_s_per_gpu": n / ((kernel_ms.get("leap", 0) + kernel_ms.get("greedy", 0)) * 1e-3),
+            "accuracy_pct": {asm.ALIGNER_NAMES[a]: 100.0 * float(cnt[1 + a]) / float(cnt[0]) for a in aligners}
+            if asm.NW in aligners else None,
+            "roofline": {
+                "bound": "hbm",
+                "kernel": dom,
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_launch_ms": kernel_ms[dom],
+                "note": "integer-VALU-bound path (SURVEY.md F7): see DESIGN.md §5 for the VALU-side ceiling",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out.update(cpu_baseline_and_parity(asm, eng, hb, batch, params, aligners, args.cpu_sample, d_pen))
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline_and_parity(asm, eng, hb, batch, params, aligners, sample, d_pen):
+    """Rank 0, N=1 only: time the oracle (CPU port of the reference algorithms, bit-identical to the compiled
+    reference — tests/test_oracle_vs_reference.py) on a bounded sample, single thread like the reference's own
+    harness, and report the GPU-vs-oracle bit-exact percentage on that sample."""
+    from tests import oracle_binding
+
+    orc = oracle_binding.load_oracle()
+    orc.set_threads(1)
+    s = min(sample, hb.n)
+    sub = hb.slice(0, s)
+    t0 = time.process_time()
+    want = {}
+    per = {}
+    for a in aligners:
+        t1 = time.process_time()
+        if a == asm.NW:
+            want[a] = orc.nw(sub, params.x, params.o, params.e)
+        elif a == asm.LEAP:
+            want[a] = orc.leap(sub, params.k, params.x, params.o, params.e)
+        else:
+            want[a] = orc.greedy(sub, params.k, params.x, params.o, params.e, mode=1)
+        per[asm.ALIGNER_NAMES[a]] = s / max(time.process_time() - t1, 1e-9)
+    cpu_s = time.process_time() - t0
+    exact = {}
+    for a in aligners:
+        got = eng.to_host(d_pen[a], batch.n)[:s]
+        exact[asm.ALIGNER_NAMES[a]] = 100.0 * float((got == want[a]).mean())
+    return {
+        "cpu_baseline": {
+            "value": s / cpu_s,
+            "unit": "read pairs/s through " + "+".join(asm.ALIGNER_NAMES[a] for a in aligners),
+            "cores": 1,
+            "kind": "port",
+            "sample": f"first {s} pairs of the same seeded batch, oracle/libasm_oracle.so, 1 thread, "
+                      f"{cpu_s:.1f} s CPU; per aligner pairs/s: " + ", ".join(f"{k} {v:.3g}" for k, v in per.items()),
+            "host_cpus": os.cpu_count(),
+        },
+        "bit_exact_pct_vs_oracle": dict(exact, sample=s),
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -127,6 +127,18 @@ int asm_align_batch(asm_handle* h, int aligner, int64_t n, const char* reads, co
 int asm_count_equal_async(asm_handle* h, const int32_t* d_a, const int32_t* d_b, int64_t n,
                           unsigned long long* d_count);
 
+/* All counters of `_run_benchmark` (benchmark_utils.h:238,249-255) in one pass over device penalty arrays:
+ * d_counters[0..3] += {total_tests, nw_correct, LEAP_correct, greedy_correct}; the correct answer of pair i is
+ * d_answers[i] when d_answers is given and != INT32_MIN (read_answer_file, benchmark_utils.h:358-368), else the NW
+ * penalty.  d_leap / d_greedy / d_answers may be NULL.  Enqueue only. */
+int asm_accuracy_async(asm_handle* h, const int32_t* d_nw, const int32_t* d_leap, const int32_t* d_greedy,
+                       const int32_t* d_answers, int64_t n, unsigned long long* d_counters);
+/* `_run_benchmark` for a whole resident batch in one call (benchmark_utils.h:231-259): optional re-pack of the
+ * resident ASCII, then every aligner whose output pointer is non-NULL, then the counters.  Enqueue only. */
+int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, int repack, int32_t* d_nw,
+                            int32_t* d_leap, int32_t* d_greedy, const int32_t* d_answers,
+                            unsigned long long* d_counters);
+
 /* ---- plain device memory helpers (so that non-torch hosts can drive the async API) --------------------- */
 int asm_device_malloc(asm_handle* h, size_t bytes, void** d_ptr);
 int asm_device_free(asm_handle* h, void* d_ptr);

@@ -97,7 +97,7 @@ def test_ragged_and_edge_lengths(asm, engine, oracle, x, o, e):
 
 
 def test_long_sequences_512(asm, engine, oracle):
-    hb = random_ragged_batch(asm, 9, 400, 300, 512, err=0.05)
+    hb = random_ragged_batch(asm, 9, 400, 300, 490, err=0.04)
     params = asm.Params.default(k=3)
     batch = engine.upload(hb, asm.GREEDY_CLEAN)
     _check("nw", engine.align(batch, asm.NW, params), oracle.nw(hb), hb)
