@@ -402,3 +402,39 @@ def declared_symbols() -> Sequence[str]:
     with open(HEADER_PATH) as fh:
         text = fh.read()
     return sorted(set(re.findall(r"\b(asm_[a-z0-9_]+)\s*\(", text)) - {"asm_handle", "asm_batch"})
+
+
+# ---- multi-GPU: read pairs are independent, so the batch shards with no data-path collective ----
+def shard_bounds(total: int, world: int, rank: int) -> Tuple[int, int]:
+    """Strong-scaling split of `total` pairs into contiguous blocks of ceil(total/world): -> [lo, hi)."""
+    per = (total + world - 1) // world
+    lo = min(rank * per, total)
+    return lo, min(lo + per, total)
+
+
+def weak_shard_first(rank: int, pairs_per_rank: int) -> int:
+    """Weak scaling: rank r owns pairs [r*n, (r+1)*n) of the seeded stream."""
+    return rank * pairs_per_rank
+
+
+def allreduce_counters(counters, dist=None):
+    """The one collective of the path: sum the {total, nw_ok, leap_ok, greedy_ok} int64 counters over ranks
+    (RCCL over xGMI on GPUs — backend "nccl"; gloo in the CPU tests).  `counters` is a torch tensor."""
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(counters)
+    return counters
+
+
+def gather_penalties(local, dist=None, dst: int = 0):
+    """Optional: collect per-shard penalty tensors on rank `dst` (direct peer links; no ring needed)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [local]
+    out = [None] * dist.get_world_size() if dist.get_rank() == dst else None
+    import torch
+
+    sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(dist.get_world_size())]
+    dist.all_gather(sizes, torch.tensor([local.numel()], dtype=torch.int64, device=local.device))
+    if dist.get_rank() == dst:
+        out = [torch.empty(int(s.item()), dtype=local.dtype, device=local.device) for s in sizes]
+    dist.gather(local, out, dst=dst) if all(int(s.item()) == local.numel() for s in sizes) else None
+    return out

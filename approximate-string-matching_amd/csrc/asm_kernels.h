@@ -79,6 +79,14 @@ struct GreedyArgs {
     double sig_match, sig_mismatch, sig_indel; /* hurdle_matrix.h:536-538, computed on the host with libm */
 };
 
+// hurdle_matrix.h:328-330.  With the default probabilities mismatch_sig == indel_sig bit for bit, so lanes that
+// trade a hurdle for a lane switch tie up to rounding, and the rounding sequence decides the arg-max.  The
+// reference built with its own flags (-O3 -march=native: GCC contracts a*b+c on FMA hardware) evaluates
+// fma(indel, nsw, fma(mismatch, nh, match*len)); the same three roundings are issued here explicitly.
+ASM_DEV double greedy_significance(const GreedyArgs& a, int len, int nh, int nsw) {
+    return __fma_rn(a.sig_indel, (double)nsw, __fma_rn(a.sig_mismatch, (double)nh, __dmul_rn(a.sig_match, (double)len)));
+}
+
 ASM_DEV V128 greedy_lane_vector(V128 A0, V128 A1, V128 B0, V128 B1, int lane) {
     const int s = lane < 0 ? -lane : lane;
     V128 m0, m1;
@@ -160,9 +168,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_kernel(const uint4* __restri
             const int hc = x * nh[j];
             const int cur_cost = -sw[j] - hc;
             // no FMA contraction: identical bits on every compiler/target (oracle is built -ffp-contract=off)
-            double heur = __dadd_rn(__dadd_rn(__dmul_rn(args.sig_match, (double)len[j]),
-                                              __dmul_rn(args.sig_mismatch, (double)nh[j])),
-                                    __dmul_rn(args.sig_indel, (double)nsw[j]));
+            double heur = greedy_significance(args, len[j], nh[j], nsw[j]);
             int leap = -sw[j];
             if (reaching) {
                 const int fsw = lane_penalty(lane, dest_lane, o, e);

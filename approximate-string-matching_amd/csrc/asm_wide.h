@@ -187,9 +187,7 @@ __global__ __launch_bounds__(ASM_WIDE_THREADS) void greedy_wide_kernel(const uin
             const int reaching = __syncthreads_or(reach);
             const int hc = x * nh;
             if (active) {
-                double heur = __dadd_rn(__dadd_rn(__dmul_rn(args.sig_match, (double)len),
-                                                  __dmul_rn(args.sig_mismatch, (double)nh)),
-                                        __dmul_rn(args.sig_indel, (double)nsw));
+                double heur = greedy_significance(args, len, nh, nsw);
                 int leap = -sw;
                 if (reaching) {
                     const int fsw = lane_penalty(lane, dest_lane, o, e);

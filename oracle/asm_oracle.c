@@ -250,7 +250,13 @@ static int greedy_pair(const uint8_t* Aview, const uint8_t* Bview, int m, int n,
         for (int lane = -k; lane <= k; lane++) {
             hw_t* h = &hw[lane + 128];
             int cur_cost = -h->sw - h->hc;
-            double heur = sig[0] * h->len + sig[1] * h->nh + sig[2] * h->nsw;
+            /* hurdle_matrix.h:328-330.  mismatch_sig == indel_sig exactly with the default probabilities
+             * (0.20/3/0.25 == 0.40/3/2/0.25), so lanes trading a hurdle for a switch tie up to rounding and the
+             * rounding sequence decides the arg-max.  The reference built with its own flags (GASMA/CMakeLists.txt:
+             * -O3 -march=native, GCC contracts a*b+c on FMA hardware) evaluates
+             *     fma(indel_sig, nsw, fma(mismatch_sig, nh, match_sig*len))
+             * (read from the disassembly of oracle/_ref); that exact sequence is restated here and in the kernels. */
+            double heur = fma(sig[2], (double)h->nsw, fma(sig[1], (double)h->nh, sig[0] * (double)h->len));
             int leap = -h->sw;
             if (reaching) {
                 int fsw = lane_penalty(lane, dest_lane, o, e);

@@ -1,0 +1,104 @@
+"""The oracle against the committed golden vectors (outputs of the compiled reference, tests/golden/make_golden.py)
+and the reference's literal known-answer pairs.  CPU only."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.util import greedy_defined, leap_defined
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+with open(os.path.join(GOLD, "index.json")) as fh:
+    INDEX = json.load(fh)
+
+
+def _digest(strings):
+    return np.array([int.from_bytes(hashlib.blake2b(s.encode(), digest_size=8).digest(), "little") for s in strings],
+                    np.uint64)
+
+
+def _inputs_sha(hb):
+    h = hashlib.sha256()
+    for a in (hb.read_off, hb.reads, hb.ref_off, hb.refs):
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def load_case(asm, name):
+    meta = INDEX["cases"][name]
+    cfg, _, _ = asm.workload(meta["workload"])
+    hb = asm.generate_pairs(cfg, meta["first"], meta["n"])
+    assert _inputs_sha(hb) == meta["inputs_sha256"], "generator output changed: regenerate the goldens deliberately"
+    return meta, hb, np.load(os.path.join(GOLD, name + ".npz"))
+
+
+@pytest.mark.parametrize("name", sorted(INDEX["cases"]))
+def test_oracle_matches_reference_goldens(asm, oracle, name):
+    meta, hb, gold = load_case(asm, name)
+    k, x, o, e = meta["k"], meta["x"], meta["o"], meta["e"]
+    gd = greedy_defined(hb, k)  # |n-m| > k is undefined in the reference
+    ld = leap_defined(hb)       # LEAP reads out of bounds beyond 256
+    for mode, tag in ((0, "seq"), (1, "clean")):
+        cost, cig = oracle.greedy(hb, k, x, o, e, mode=mode, cigars=True)
+        assert np.array_equal(cost[gd], gold[f"greedy_{tag}_cost"][gd]), (name, tag)
+        assert np.array_equal(_digest(cig)[gd], gold[f"greedy_{tag}_cigar"][gd]), (name, tag, "CIGAR")
+    assert np.array_equal(oracle.leap(hb, k, x, o, e)[ld], gold["leap_ed"][ld]), name
+    nw = oracle.nw(hb.slice(0, meta["nw_first"]), x, o, e)
+    assert np.array_equal(nw, gold["nw_first"]), (name, "NW vs independent pure-Python Gotoh")
+    assert gd.mean() > 0.99 and (ld.mean() > 0.99 or meta["workload"] == "C5")
+
+
+def test_known_answer_vectors(asm, oracle):
+    """Literal pairs from the reference tree (GASMA/main.cpp:7-8,14-15; pymatch/algorithms/LEAP.py:188)."""
+    for key, ka in INDEX["known_answers"].items():
+        hb = asm.HostBatch.from_strings([(ka["read"], ka["ref"])])
+        assert int(oracle.nw(hb)[0]) == ka["nw"] == int(oracle.levenshtein(hb)[0]), key
+        for k in (2, 3):
+            if key == "KA-1":
+                continue  # |n-m| = 4 > k: characterisation only
+            cost, cig = oracle.greedy(hb, k=k, mode=1, cigars=True)
+            assert (int(cost[0]), cig[0]) == (ka[f"greedy_k{k}"], ka[f"greedy_cigar_k{k}"]), (key, k)
+            assert int(oracle.leap(hb, k=k)[0]) == ka[f"leap_k{k}"], (key, k)
+    ka0 = INDEX["known_answers"]["KA-0"]
+    assert ka0["greedy_cigar_k3"] == "22M1D50M1D28M" and ka0["greedy_k3"] == 6  # the demo of GASMA/main.cpp
+    ka5 = INDEX["known_answers"]["KA-5"]
+    assert ka5["leap_k3"] == 2 and ka5["nw"] == 3  # LEAP's final_ED omits the last lane switch
+
+
+def test_nw_is_levenshtein_for_unit_costs(asm, oracle):
+    cfg, _, _ = asm.workload("C5")
+    hb = asm.generate_pairs(cfg, 1000, 300)
+    assert np.array_equal(oracle.nw(hb, 1, 1, 1), oracle.levenshtein(hb))
+
+
+def test_readme_accuracy_statistics(asm, oracle):
+    """Statistical pin against the reference's published accuracy at err=0.10 (README.md:32-34: LEAP 98.066 %,
+    Greedy 78.020 %)."""
+    cfg, _, _ = asm.workload("C2")
+    hb = asm.generate_pairs(cfg, 0, 40000)
+    nw = oracle.nw(hb)
+    leap_acc = float((oracle.leap(hb, 3) == nw).mean()) * 100
+    greedy_acc = float((oracle.greedy(hb, 3, mode=0) == nw).mean()) * 100
+    assert abs(leap_acc - 98.066) < 0.5 and abs(greedy_acc - 78.020) < 1.0, (leap_acc, greedy_acc)
+
+
+def test_coverage_metric_and_nw_cigar(asm, oracle):
+    """benchmark_coverage.h semantics + consistency of the oracle's own NW traceback."""
+    cfg, _, _ = asm.workload("C2")
+    hb = asm.generate_pairs(cfg, 0, 2000)
+    pen, ncig = oracle.nw_cigar(hb)
+    assert np.array_equal(pen, oracle.nw(hb))
+    # a CIGAR's cost recomputed from its ops equals the penalty, and it consumes both strings fully
+    import re
+
+    for i in range(0, 2000, 97):
+        ops = re.findall(r"(\d+)([=XID])", ncig[i])
+        a, b = hb.pair(i)
+        assert sum(int(c) for c, t in ops if t in "=XI") == len(a) and sum(int(c) for c, t in ops if t in "=XD") == len(b)
+        assert sum(int(c) if t == "X" else (1 + (int(c) - 1)) if t in "ID" else 0 for c, t in ops) == pen[i]
+    gcost, gcig = oracle.greedy(hb, 3, mode=1, cigars=True)
+    cov = oracle.coverage(hb, gcig, 1, ncig, 3)
+    assert 0.85 < cov.mean() <= 1.0  # README.md:36 reports 94.2 % with parasail's traceback (unpinned tie-break)
+    assert oracle.coverage(hb, ncig, 1, ncig, 3).all()  # an alignment covers itself
