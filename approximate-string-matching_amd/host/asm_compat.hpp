@@ -1,0 +1,226 @@
+// Header-only C++ host side over the C ABI (include/asm_mi355x.h), mirroring the reference's interface for the
+// hot path so that code written against the reference reads the same:
+//   hurdle_matrix<T>  reset/run/get_cost           GASMA/hurdle_matrix.h:552-562,568,625,667,677
+//   LV                init/load_reads/reset/run/check_pass/get_ED   GASMA/benchmark/LEAP_SIMD/LV_BAG.h:40-54
+//   benchmark         read_string_file/read_answer_file/run/print   GASMA/benchmark/benchmark_utils.h:263-402
+//   Dataset           output()                                       GASMA/benchmark/benchmark_dataset.h:189-253
+// Same names, argument meaning and (absence of an) error channel as the reference, except that failures of
+// the device library throw std::runtime_error instead of being ignored.  Everything computes on the GPU through
+// libasm_mi355x.so; there is no CPU path.  The per-pair classes launch one-pair batches (kept for interface
+// compatibility; slow by construction) — the performance path is `benchmark`, which runs the whole file as one batch.
+#pragma once
+#include <climits>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "asm_mi355x.h"
+
+namespace asm_amd {
+
+enum alignment_type_t { GLOBAL, SEMI_GLOBAL, LOCAL };                            // GASMA/utils.h:554-558
+enum ED_modes { ED_LOCAL, ED_GLOBAL, ED_SEMI_FREE_BEGIN, ED_SEMI_FREE_END };     // LEAP_SIMD/LV_BAG.h:38
+struct int_128bit {};                                                            // tag only: vectors live on the GPU
+
+inline void check(asm_handle* h, int rc) {
+    if (rc != ASM_OK) throw std::runtime_error(std::string("asm_mi355x: ") + asm_last_error(h));
+}
+
+// One handle per process and GPU, shared by the compat objects.
+inline asm_handle* shared_handle(int device = 0) {
+    static asm_handle* h = nullptr;
+    if (!h) check(nullptr, asm_create(&h, device));
+    return h;
+}
+
+inline int align_one(int aligner, const char* read, int m, const char* ref, int n, const asm_params& p, int mode) {
+    uint32_t ro[2] = {0u, (uint32_t)m}, fo[2] = {0u, (uint32_t)n};
+    int32_t out = 0;
+    asm_handle* h = shared_handle();
+    check(h, asm_align_batch(h, aligner, 1, read, ro, ref, fo, &p, mode, &out));
+    return out;
+}
+
+template <typename T = int_128bit>
+class hurdle_matrix {
+    asm_params p_;
+    std::string read_, ref_;
+    int cost_ = 0;
+
+public:
+    explicit hurdle_matrix(alignment_type_t type = GLOBAL, int x = 1, int o = 1, int e = 1, double match_prob = 0.80,
+                           double mismatch_prob = 0.20 / 3, double indel_prob = 0.40 / 3) {
+        if (type != GLOBAL) throw std::runtime_error("hurdle_matrix: only GLOBAL is on the accelerated path");
+        asm_default_params(&p_);
+        p_.x = x, p_.o = o, p_.e = e;
+        p_.p_match = match_prob, p_.p_mismatch = mismatch_prob, p_.p_indel = indel_prob;
+    }
+    void reset(const char* read, const int read_len, const char* ref, const int ref_len, int error) {
+        read_.assign(read, (size_t)read_len);
+        ref_.assign(ref, (size_t)ref_len);
+        p_.k = error;
+    }
+    void reset(const char* read, const char* ref, int error) { reset(read, (int)strlen(read), ref, (int)strlen(ref), error); }
+    // A lone object has no batch history: tails are clean (the reference's are indeterminate for a first pair).
+    void run() { cost_ = align_one(ASM_GREEDY, read_.data(), (int)read_.size(), ref_.data(), (int)ref_.size(), p_, ASM_GREEDY_CLEAN); }
+    int get_cost() const { return cost_; }
+};
+
+class LV {
+    asm_params p_;
+    std::string read_, ref_;
+    int ed_ = -1;
+
+public:
+    LV() { asm_default_params(&p_); }
+    void init(int gap_threshold, int af_threshold, ED_modes mode, int ms_penalty, int gap_open_penalty, int gap_ext_penalty) {
+        if (mode != ED_GLOBAL || af_threshold != ASM_LEAP_AF_THRESHOLD)
+            throw std::runtime_error("LV::init: the accelerated path is ED_GLOBAL with af_threshold 200 (benchmark_utils.h:289)");
+        p_.k = gap_threshold, p_.x = ms_penalty, p_.o = gap_open_penalty, p_.e = gap_ext_penalty;
+    }
+    void load_reads(char* read, char* ref, int length) {  // NUL-terminated inputs, as the harness passes them
+        read_.assign(read, strnlen(read, (size_t)length));
+        ref_.assign(ref, strnlen(ref, (size_t)length));
+    }
+    void reset() { ed_ = -1; }
+    void run() { ed_ = align_one(ASM_LEAP, read_.data(), (int)read_.size(), ref_.data(), (int)ref_.size(), p_, ASM_GREEDY_CLEAN); }
+    bool check_pass() const { return ed_ >= 0; }
+    int get_ED() const { return ed_; }
+};
+
+// Seeded counterpart of `Dataset` (writes the same ">read\n<ref\n" file; the seed replaces time()).
+class Dataset {
+    asm_gen_config cfg_{};
+    int num_reads_;
+
+public:
+    Dataset(int num_reads, int length, float error_rate, float mismatch_rate, bool exact_error_rate = true, uint64_t seed = 1) {
+        if (!exact_error_rate) throw std::runtime_error("Dataset: only exact_error_rate=true is restated");
+        cfg_.seed = seed, cfg_.kind = ASM_GEN_EXACT_ERRORS, cfg_.len_lo = cfg_.len_hi = length;
+        cfg_.err = error_rate, cfg_.mismatch_rate = mismatch_rate;
+        num_reads_ = num_reads;
+    }
+    const asm_gen_config& config() const { return cfg_; }
+    void output(const char* path) const {
+        std::vector<uint32_t> ro((size_t)num_reads_ + 1), fo((size_t)num_reads_ + 1);
+        check(nullptr, asm_generate_pairs(&cfg_, 0, num_reads_, ro.data(), fo.data(), nullptr, 0, nullptr, 0));
+        std::vector<char> reads(ro.back() + 1), refs(fo.back() + 1);
+        check(nullptr, asm_generate_pairs(&cfg_, 0, num_reads_, ro.data(), fo.data(), reads.data(), reads.size(), refs.data(), refs.size()));
+        FILE* f = fopen(path, "w");
+        if (!f) throw std::runtime_error(std::string("Dataset: cannot write ") + path);
+        for (int i = 0; i < num_reads_; i++) {
+            fprintf(f, ">%.*s\n<%.*s\n", (int)(ro[i + 1] - ro[i]), reads.data() + ro[i], (int)(fo[i + 1] - fo[i]), refs.data() + fo[i]);
+        }
+        fclose(f);
+    }
+    std::string output() const {  // benchmark_dataset.h:242-253 file name, plus the seed
+        std::string name = "simulated_" + std::to_string(num_reads_) + "_" + std::to_string(cfg_.len_lo) + "_" +
+                           std::to_string(cfg_.err) + "_eq_seed" + std::to_string(cfg_.seed) + ".seq";
+        output(name.c_str());
+        return name;
+    }
+};
+
+class benchmark {
+    asm_params p_;
+    int max_tests_;
+    int greedy_mode_;
+    std::vector<char> reads_, refs_;
+    std::vector<uint32_t> ro_{0}, fo_{0};
+    std::vector<int32_t> answers_;
+    unsigned long long counters_[4] = {0, 0, 0, 0};
+    float ms_[3] = {0, 0, 0};
+    std::vector<int32_t> pen_[3];
+
+public:
+    // benchmark_utils.h:263-269; greedy_mode: ASM_GREEDY_SEQUENTIAL reproduces the reference's run order dependence
+    benchmark(int x, int o, int e, int k, int max_test_num, bool /*use_SIMD*/ = true, int greedy_mode = ASM_GREEDY_SEQUENTIAL)
+        : max_tests_(max_test_num), greedy_mode_(greedy_mode) {
+        asm_default_params(&p_);
+        p_.x = x, p_.o = o, p_.e = e, p_.k = k;
+    }
+    // benchmark_utils.h:325-352: the first character of every line is skipped blindly
+    void read_string_file(const char* path, bool skip_first_char = true) {
+        std::ifstream in(path);
+        if (!in.is_open()) {
+            printf("Unable to open data file: %s\n", path);
+            return;
+        }
+        std::string a, b;
+        int i = 0;
+        for (; i < max_tests_; i++) {
+            if (!std::getline(in, a)) break;
+            std::getline(in, b);
+            const size_t s = skip_first_char ? 1 : 0;
+            if (a.size() >= s) reads_.insert(reads_.end(), a.begin() + s, a.end());
+            if (b.size() >= s) refs_.insert(refs_.end(), b.begin() + s, b.end());
+            ro_.push_back((uint32_t)reads_.size());
+            fo_.push_back((uint32_t)refs_.size());
+        }
+        max_tests_ = i;
+        printf("Processed data file: %s\n", path);
+    }
+    // benchmark_utils.h:358-368
+    void read_answer_file(const char* path) {
+        std::ifstream in(path);
+        std::string line;
+        answers_.assign((size_t)max_tests_, INT32_MIN);
+        for (int i = 0; i < max_tests_ && std::getline(in, line); i++) answers_[(size_t)i] = atoi(line.c_str());
+    }
+    // benchmark_utils.h:373-385 — the whole file as ONE batch on the GPU
+    void run() {
+        asm_handle* h = shared_handle();
+        const int64_t n = (int64_t)ro_.size() - 1;
+        asm_batch* b = nullptr;
+        check(h, asm_batch_upload(h, n, reads_.data(), ro_.data(), refs_.data(), fo_.data(), greedy_mode_, &b));
+        void *d_pen[3], *d_cnt = nullptr, *d_ans = nullptr, *tm = nullptr;
+        for (auto& d : d_pen) check(h, asm_device_malloc(h, sizeof(int32_t) * (size_t)(n > 0 ? n : 1), &d));
+        check(h, asm_device_malloc(h, 32, &d_cnt));
+        check(h, asm_memset_async(h, d_cnt, 0, 32));
+        if (!answers_.empty()) {
+            check(h, asm_device_malloc(h, sizeof(int32_t) * answers_.size(), &d_ans));
+            check(h, asm_memcpy_h2d(h, d_ans, answers_.data(), sizeof(int32_t) * answers_.size()));
+        }
+        check(h, asm_timer_create(h, &tm));
+        for (int a = 0; a < 3; a++) {
+            check(h, asm_timer_start(h, tm));
+            check(h, asm_align_batch_async(h, b, a, &p_, (int32_t*)d_pen[a]));
+            check(h, asm_timer_stop(h, tm));
+            check(h, asm_timer_elapsed_ms(h, tm, &ms_[a]));
+        }
+        check(h, asm_accuracy_async(h, (int32_t*)d_pen[0], (int32_t*)d_pen[1], (int32_t*)d_pen[2], (int32_t*)d_ans, n,
+                                    (unsigned long long*)d_cnt));
+        check(h, asm_memcpy_d2h(h, counters_, d_cnt, 32));
+        for (int a = 0; a < 3; a++) {
+            pen_[a].resize((size_t)n);
+            if (n) check(h, asm_memcpy_d2h(h, pen_[a].data(), d_pen[a], sizeof(int32_t) * (size_t)n));
+            asm_device_free(h, d_pen[a]);
+        }
+        asm_device_free(h, d_cnt);
+        if (d_ans) asm_device_free(h, d_ans);
+        asm_timer_destroy(h, tm);
+        asm_batch_free(h, b);
+        printf("...complete.\n");
+    }
+    const std::vector<int32_t>& penalties(int aligner) const { return pen_[aligner]; }
+    // benchmark_utils.h:390-402 — same block; [Time] is GPU kernel time (HIP events) instead of CPU user time
+    void print() const {
+        const double total = (double)counters_[0];
+        printf("===================== Benchmark Results =====================\n");
+        printf("Total number of alignments: %d\n[Time]\n", (int)counters_[0]);
+        printf("=> Needleman-Wunsch | %.3f s\n", ms_[0] * 1e-3);
+        printf("=> LEAP             | %.3f s\n", ms_[1] * 1e-3);
+        printf("=> Greedy           | %.3f s\n", ms_[2] * 1e-3);
+        printf("[Accuracy] (percentage of alignments matching optimal penalty)\n");
+        printf("=> Needleman-Wunsch | %.3f %%\n", (double)counters_[1] / total * 100);
+        printf("=> LEAP             | %.3f %%\n", (double)counters_[2] / total * 100);
+        printf("=> Greedy           | %.3f %%\n", (double)counters_[3] / total * 100);
+        printf("[Coverage] (percentage of alignments covering all long consecutive matches)\n");
+        printf("=> Greedy           | not computed (CIGAR/coverage row is not on the device path yet)\n");
+    }
+};
+
+}  // namespace asm_amd
