@@ -148,3 +148,29 @@ def test_count_equal(asm, engine, oracle):
     assert cnt == int((oracle.nw(hb) == oracle.leap(hb, k=3)).sum())
     for p in (d_nw, d_leap, d_cnt):
         engine.free(p)
+
+
+def test_asm_bench_harness_prints_reference_block(asm, oracle, tmp_path):
+    """The C++ host side (host/asm_compat.hpp + asm-bench, counterpart of GASMA/benchmark/benchmark.cpp): reads a
+    '>read\\n<ref\\n' file, runs the batch on the GPU, prints the reference's results block (benchmark_utils.h:390-402)."""
+    import os
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(asm.LIB_PATH), "asm-bench")
+    cfg, _, _ = asm.workload("C2")
+    hb = asm.generate_pairs(cfg, 0, 20000)
+    path = str(tmp_path / "pairs.seq")
+    hb.write_seq_file(path)
+    nw = oracle.nw(hb)
+    (tmp_path / "answers.txt").write_text("\n".join(str(int(v)) for v in nw) + "\n")
+    for extra, mode in (([], 0), (["--answers", str(tmp_path / "answers.txt")], 0), (["--mode", "clean"], 1)):
+        out = subprocess.check_output([exe, "--file", path, "--n", "20000", "--k", "3"] + extra, text=True)
+        lines = out.splitlines()
+        assert "===================== Benchmark Results =====================" in lines
+        assert "Total number of alignments: 20000" in lines
+        assert "[Accuracy] (percentage of alignments matching optimal penalty)" in lines
+        want = {"Needleman-Wunsch": 100.0, "LEAP": 100.0 * float((oracle.leap(hb, 3) == nw).mean()),
+                "Greedy": 100.0 * float((oracle.greedy(hb, 3, mode=mode) == nw).mean())}
+        acc = lines[lines.index("[Accuracy] (percentage of alignments matching optimal penalty)") + 1:][:3]
+        for line, (name, val) in zip(acc, want.items()):
+            assert line == "=> %-16s | %.3f %%" % (name, val), (line, name, val)
