@@ -205,12 +205,17 @@ int asm_batch_pack_async(asm_handle* h, asm_batch* b) {
     if (!h || !b) return fail(h, ASM_EINVAL, "asm_batch_pack_async: NULL argument");
     if (b->n == 0) return ASM_OK;
     HIPCHK(h, hipSetDevice(h->device));
-    /* one wave per pair, grid capped: 256 CUs x 8 blocks, 4 waves per block */
-    int64_t waves = b->n;
-    int64_t blocks = (waves + 3) / 4;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)blocks), dim3(ASM_BLOCK), 0, h->stream, b->d_reads, b->d_read_off,
-                       b->d_refs, b->d_ref_off, b->d_tails, b->d_planes, b->d_lens, (long)b->n, b->w4);
+    const dim3 grid((unsigned)((b->n + ASM_BLOCK - 1) / ASM_BLOCK)), block(ASM_BLOCK);
+#define PACK_LAUNCH(W)                                                                                            \
+    hipLaunchKernelGGL(pack_kernel<W>, grid, block, 0, h->stream, b->d_reads, b->d_read_off, b->d_refs, b->d_ref_off, \
+                       b->d_tails, b->d_planes, b->d_lens, (long)b->n, b->w4)
+    switch (b->w4) {
+        case 1: PACK_LAUNCH(1); break;
+        case 2: PACK_LAUNCH(2); break;
+        case 3: PACK_LAUNCH(3); break;
+        default: PACK_LAUNCH(4); break;
+    }
+#undef PACK_LAUNCH
     HIPCHK(h, hipGetLastError());
     return ASM_OK;
 }

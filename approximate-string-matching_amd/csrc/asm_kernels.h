@@ -25,9 +25,22 @@
 // --------------------------------------------------------------------------------------------------------
 // Pack: ASCII -> bit planes.  Device counterpart of sse3_convert2bit1 (GASMA/bit_convert.cpp:248-369), minus
 // its in-place byte permutation (whose only observable effect, the stale tails of later pairs, is supplied
-// through `tails` in sequential mode — see asm_tails.h).  One wave per pair: lane l looks at characters l and
-// l+64 of a granule for both strings, and four __ballot()s per half produce 64 bits of each plane at once.
+// through `tails` in sequential mode — see asm_tails.h).
+//
+// A workgroup owns 256 consecutive pairs.  Their ASCII is one contiguous byte range of the batch, so it is
+// staged into LDS with fully coalesced 16 B/lane loads (a thread-per-pair gather straight from HBM would touch
+// ~50 cache lines per load instruction); then every thread converts its own string out of LDS, four characters
+// per dword with SWAR byte compares (exactly 'C','G','T' set bits; every other byte is code 00).  The staging
+// buffer is XOR-swizzled per 128-byte row so that strings whose length is a multiple of 128 B do not all hit
+// one LDS bank.  Long batches are staged in rounds of whole pairs that fit the buffer.
 // --------------------------------------------------------------------------------------------------------
+#define PACK_SB (48 * 1024)
+
+ASM_DEV uint32_t swar_zero_bytes(uint32_t t) { /* bit 7 of each byte set iff that byte of t is zero (exact) */
+    return ~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t | 0x7f7f7f7fu);
+}
+
+template <int W4>
 __global__ __launch_bounds__(ASM_BLOCK) void pack_kernel(const char* __restrict__ reads,
                                                          const uint32_t* __restrict__ read_off,
                                                          const char* __restrict__ refs,
@@ -35,37 +48,88 @@ __global__ __launch_bounds__(ASM_BLOCK) void pack_kernel(const char* __restrict_
                                                          const uint4* __restrict__ tails, /* [4][n] or null */
                                                          uint4* __restrict__ planes, uint32_t* __restrict__ lens,
                                                          long n, int w4) {
-    const int lane = threadIdx.x & 63;
-    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
-    for (long i = wave; i < n; i += nwaves) {
-        const uint32_t ra = read_off[i], rb = ref_off[i];
-        const int m = (int)(read_off[i + 1] - ra), nn = (int)(ref_off[i + 1] - rb);
-        if (lane == 0) lens[i] = (uint32_t)m | ((uint32_t)nn << 16);
-        for (int g = 0; g < w4; g++) {
-            u64 bits[4][2];
+    __shared__ uint4 s_buf[PACK_SB / 16 + 4];
+    __shared__ uint32_t s_off[ASM_BLOCK + 1];
+    const int t = threadIdx.x;
+    const long p0 = (long)blockIdx.x * ASM_BLOCK;
+    const int np = (n - p0) < ASM_BLOCK ? (int)(n - p0) : ASM_BLOCK;
+    const uint32_t* sb = reinterpret_cast<const uint32_t*>(s_buf);
+    uint32_t my_len[2] = {0u, 0u};
+#pragma unroll 1
+    for (int s = 0; s < 2; s++) {
+        const char* str = s ? refs : reads;
+        const uint32_t* off = s ? ref_off : read_off;
+        __syncthreads();
+        s_off[t] = off[p0 + (t < np ? t : np)];
+        if (t == 0) s_off[ASM_BLOCK] = off[p0 + np];
+        __syncthreads();
+        const uint32_t o0 = s_off[t], o1 = s_off[t + 1];
+        const int len = (int)(o1 - o0);
+        my_len[s] = (uint32_t)len;
+        int ps = 0;
+        while (ps < np) { /* uniform across the workgroup */
+            const uint32_t base = s_off[ps] & ~15u;
+            const int fits = (t >= ps && t < np && (o1 - base) <= (uint32_t)PACK_SB) ? 1 : 0;
+            const int pe = ps + __syncthreads_count(fits); /* offsets are monotone: the fitting pairs are [ps, pe) */
+            const uint32_t hi = s_off[pe];
+            const int nvec = (int)((hi - base + 15u) >> 4);
+            const uint4* src = reinterpret_cast<const uint4*>(str + base);
+            for (int v = t; v < nvec; v += ASM_BLOCK) {
+                const int a = 4 * v;
+                s_buf[(a ^ (((a >> 5) & 7) << 2)) >> 2] = src[v];
+            }
+            __syncthreads();
+            if (t >= ps && t < pe) {
+                const uint32_t b0 = o0 - base;
+                const int a0 = (int)(b0 >> 2);
+                const uint32_t sh = (b0 & 3u) * 8u;
 #pragma unroll
-            for (int half = 0; half < 2; half++) {
-                const int pos = g * 128 + half * 64 + lane;
-                const char ca = pos < m ? reads[ra + pos] : (char)0;
-                const char cb = pos < nn ? refs[rb + pos] : (char)0;
-                bits[0][half] = __ballot(ca == 'C' || ca == 'T');
-                bits[1][half] = __ballot(ca == 'G' || ca == 'T');
-                bits[2][half] = __ballot(cb == 'C' || cb == 'T');
-                bits[3][half] = __ballot(cb == 'G' || cb == 'T');
-            }
-            if (lane < 4) {
-                u64 lo = lane == 0 ? bits[0][0] : lane == 1 ? bits[1][0] : lane == 2 ? bits[2][0] : bits[3][0];
-                u64 hi = lane == 0 ? bits[0][1] : lane == 1 ? bits[1][1] : lane == 2 ? bits[2][1] : bits[3][1];
-                uint4 q = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
-                if (tails != nullptr && g == 0) {
-                    const uint4 t = tails[(long)lane * n + i];
-                    q.x |= t.x, q.y |= t.y, q.z |= t.z, q.w |= t.w;
+                for (int g = 0; g < W4; g++) {
+                    if (g < w4) {
+                        uint32_t q0[4] = {0u, 0u, 0u, 0u}, q1[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                        for (int w = 0; w < 4; w++) {
+                            const int cbase = g * 128 + w * 32;
+                            if (cbase < len) {
+                                uint32_t d[9];
+#pragma unroll
+                                for (int q = 0; q < 9; q++) {
+                                    const int a = a0 + (cbase >> 2) + q;
+                                    d[q] = sb[a ^ (((a >> 5) & 7) << 2)];
+                                }
+#pragma unroll
+                                for (int q = 0; q < 8; q++) {
+                                    uint32_t ch = __builtin_amdgcn_alignbit(d[q + 1], d[q], sh);
+                                    const int rem = len - (cbase + 4 * q);
+                                    const uint32_t vm = rem >= 4 ? ~0u : (rem <= 0 ? 0u : (0xffffffffu >> (32 - 8 * rem)));
+                                    ch &= vm;
+                                    const uint32_t x = ch ^ 0x43434343u; /* 'C' */
+                                    const uint32_t fC = swar_zero_bytes(x);
+                                    const uint32_t fG = swar_zero_bytes(x ^ 0x04040404u); /* 'G' = 'C' ^ 0x04 */
+                                    const uint32_t fT = swar_zero_bytes(x ^ 0x17171717u); /* 'T' = 'C' ^ 0x17 */
+                                    /* gather the four byte flags (bits 7,15,23,31) into a nibble */
+                                    q0[w] |= (((fC | fT) * 0x00204081u) >> 28) << (4 * q);
+                                    q1[w] |= (((fG | fT) * 0x00204081u) >> 28) << (4 * q);
+                                }
+                            }
+                        }
+                        uint4 v0 = make_uint4(q0[0], q0[1], q0[2], q0[3]);
+                        uint4 v1 = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+                        if (tails != nullptr && g == 0) {
+                            const uint4 t0 = tails[(long)(2 * s) * n + p0 + t], t1 = tails[(long)(2 * s + 1) * n + p0 + t];
+                            v0.x |= t0.x, v0.y |= t0.y, v0.z |= t0.z, v0.w |= t0.w;
+                            v1.x |= t1.x, v1.y |= t1.y, v1.z |= t1.z, v1.w |= t1.w;
+                        }
+                        planes[((long)(2 * s) * w4 + g) * n + p0 + t] = v0;
+                        planes[((long)(2 * s + 1) * w4 + g) * n + p0 + t] = v1;
+                    }
                 }
-                planes[((long)lane * w4 + g) * n + i] = q;
             }
+            __syncthreads();
+            ps = pe;
         }
     }
+    if (t < np) lens[p0 + t] = my_len[0] | (my_len[1] << 16);
 }
 
 // --------------------------------------------------------------------------------------------------------
