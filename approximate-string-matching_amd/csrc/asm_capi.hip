@@ -5,6 +5,7 @@
 #include <hipcub/hipcub.hpp>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -20,7 +21,15 @@ struct asm_handle {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::string err;
+    int num_cus = 256;
+    bool persist = true;                  /* Greedy: lane-refilling persistent kernel (ASM_PERSIST=0 disables) */
+    bool persist_leap = false;            /* LEAP: the plain one-pair-per-thread kernel is faster at 1e6 pairs (ASM_PERSIST_LEAP=1) */
+    int refill_greedy = 8, refill_leap = 16; /* lanes that must be idle before a wave refills (tunable by env) */
+    bool nw_banded = true;                /* banded bit-parallel NW with in-kernel full-height recompute (ASM_NW_BANDED=0) */
+    unsigned long long* d_work = nullptr; /* work-queue heads for the persistent kernels */
+    unsigned work_slot = 0;
 };
+#define ASM_WORK_SLOTS 64
 
 struct asm_batch {
     int64_t n = 0;
@@ -56,20 +65,43 @@ static int fail(asm_handle* h, int code, const std::string& msg) {
 
 static int grid_for(int64_t n) { return (int)((n + ASM_BLOCK - 1) / ASM_BLOCK); }
 
-template <int K>
-static void launch_greedy(asm_handle* h, const asm_batch* b, const GreedyArgs& ga, int32_t* d_out) {
-    hipLaunchKernelGGL(greedy_kernel<K>, dim3(grid_for(b->n)), dim3(ASM_BLOCK), 0, h->stream, b->d_planes, b->d_lens,
-                       (long)b->n, b->w4, ga, d_out);
+// Persistent launch: grid = what is resident (CUs x occupancy); each wave owns a static slice of the batch.
+template <typename Kern, typename... Args>
+static hipError_t launch_persistent(asm_handle* h, Kern kern, int64_t n, Args... args) {
+    int per_cu = 1;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, ASM_BLOCK, 0);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    int64_t blocks = (int64_t)per_cu * h->num_cus;
+    const int64_t need = (n + ASM_BLOCK - 1) / ASM_BLOCK;
+    if (blocks > need) blocks = need;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(ASM_BLOCK), 0, h->stream, args...);
+    return hipGetLastError();
 }
 
 template <int K>
-static void launch_leap_unit(asm_handle* h, const asm_batch* b, int32_t* d_out) {
-    if (b->maxlen <= 128)
-        hipLaunchKernelGGL((leap_unit_kernel<K, 2>), dim3(grid_for(b->n)), dim3(ASM_BLOCK), 0, h->stream, b->d_planes,
-                           b->d_lens, (long)b->n, b->w4, d_out);
-    else
-        hipLaunchKernelGGL((leap_unit_kernel<K, 4>), dim3(grid_for(b->n)), dim3(ASM_BLOCK), 0, h->stream, b->d_planes,
-                           b->d_lens, (long)b->n, b->w4, d_out);
+static hipError_t launch_greedy(asm_handle* h, const asm_batch* b, const GreedyArgs& ga, int32_t* d_out) {
+    if (h->persist)
+        return launch_persistent(h, greedy_persist_kernel<K>, b->n, (const uint4*)b->d_planes, (const uint32_t*)b->d_lens,
+                                 (long)b->n, b->w4, ga, d_out, h->refill_greedy);
+    hipLaunchKernelGGL(greedy_kernel<K>, dim3(grid_for(b->n)), dim3(ASM_BLOCK), 0, h->stream, b->d_planes, b->d_lens,
+                       (long)b->n, b->w4, ga, d_out);
+    return hipGetLastError();
+}
+
+template <int K, int W64>
+static hipError_t launch_leap_unit_w(asm_handle* h, const asm_batch* b, int32_t* d_out) {
+    if (h->persist_leap)
+        return launch_persistent(h, leap_unit_persist_kernel<K, W64>, b->n, (const uint4*)b->d_planes,
+                                 (const uint32_t*)b->d_lens, (long)b->n, b->w4, d_out, h->refill_leap);
+    hipLaunchKernelGGL((leap_unit_kernel<K, W64>), dim3(grid_for(b->n)), dim3(ASM_BLOCK), 0, h->stream, b->d_planes,
+                       b->d_lens, (long)b->n, b->w4, d_out);
+    return hipGetLastError();
+}
+
+template <int K>
+static hipError_t launch_leap_unit(asm_handle* h, const asm_batch* b, int32_t* d_out) {
+    return b->maxlen <= 128 ? launch_leap_unit_w<K, 2>(h, b, d_out) : launch_leap_unit_w<K, 4>(h, b, d_out);
 }
 
 extern "C" {
@@ -103,6 +135,16 @@ int asm_create(asm_handle** out, int device) {
     HIPCHK(h, hipSetDevice(device));
     HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
+    hipDeviceProp_t prop;
+    HIPCHK(h, hipGetDeviceProperties(&prop, device));
+    h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIPCHK(h, hipMalloc((void**)&h->d_work, sizeof(unsigned long long) * ASM_WORK_SLOTS));
+    const char* env = getenv("ASM_PERSIST");
+    h->persist = !(env && env[0] == '0');
+    if ((env = getenv("ASM_PERSIST_LEAP"))) h->persist_leap = env[0] != '0';
+    if ((env = getenv("ASM_NW_BANDED"))) h->nw_banded = env[0] != '0';
+    if ((env = getenv("ASM_REFILL_GREEDY"))) h->refill_greedy = atoi(env);
+    if ((env = getenv("ASM_REFILL_LEAP"))) h->refill_leap = atoi(env);
     *out = h;
     return ASM_OK;
 }
@@ -111,6 +153,7 @@ int asm_destroy(asm_handle* h) {
     if (!h) return ASM_OK;
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    (void)hipFree(h->d_work);
     delete h;
     return ASM_OK;
 }
@@ -441,21 +484,21 @@ int asm_align_batch_async(asm_handle* h, const asm_batch* b, int aligner, const 
         ga.sig_mismatch = log(p->p_mismatch / 0.25);
         ga.sig_indel = log(p->p_indel / 2 / 0.25);
         switch (p->k) {
-            case 1: launch_greedy<1>(h, b, ga, d_penalties); break;
-            case 2: launch_greedy<2>(h, b, ga, d_penalties); break;
-            case 3: launch_greedy<3>(h, b, ga, d_penalties); break;
-            case 4: launch_greedy<4>(h, b, ga, d_penalties); break;
-            case 5: launch_greedy<5>(h, b, ga, d_penalties); break;
+            case 1: HIPCHK(h, launch_greedy<1>(h, b, ga, d_penalties)); break;
+            case 2: HIPCHK(h, launch_greedy<2>(h, b, ga, d_penalties)); break;
+            case 3: HIPCHK(h, launch_greedy<3>(h, b, ga, d_penalties)); break;
+            case 4: HIPCHK(h, launch_greedy<4>(h, b, ga, d_penalties)); break;
+            case 5: HIPCHK(h, launch_greedy<5>(h, b, ga, d_penalties)); break;
             default: launch_greedy_wide(h->stream, b->d_planes, b->d_lens, b->n, b->w4, p->k, ga, d_penalties); break;
         }
     } else if (aligner == ASM_LEAP) {
         if (unit && p->k >= 1 && p->k <= 5 && b->maxlen <= 256) {
             switch (p->k) {
-                case 1: launch_leap_unit<1>(h, b, d_penalties); break;
-                case 2: launch_leap_unit<2>(h, b, d_penalties); break;
-                case 3: launch_leap_unit<3>(h, b, d_penalties); break;
-                case 4: launch_leap_unit<4>(h, b, d_penalties); break;
-                default: launch_leap_unit<5>(h, b, d_penalties); break;
+                case 1: HIPCHK(h, launch_leap_unit<1>(h, b, d_penalties)); break;
+                case 2: HIPCHK(h, launch_leap_unit<2>(h, b, d_penalties)); break;
+                case 3: HIPCHK(h, launch_leap_unit<3>(h, b, d_penalties)); break;
+                case 4: HIPCHK(h, launch_leap_unit<4>(h, b, d_penalties)); break;
+                default: HIPCHK(h, launch_leap_unit<5>(h, b, d_penalties)); break;
             }
         } else {
             launch_leap_wide(h->stream, b->d_planes, b->d_lens, b->n, b->w4, p->k, p->x, p->o, p->e, d_penalties);
@@ -463,14 +506,23 @@ int asm_align_batch_async(asm_handle* h, const asm_batch* b, int aligner, const 
     } else {
         if (unit) {
             const dim3 g(grid_for(b->n)), t(ASM_BLOCK);
-            if (b->maxlen <= 128)
-                hipLaunchKernelGGL(nw_unit_kernel<2>, g, t, 0, h->stream, b->d_planes, b->d_lens, (long)b->n, b->w4, d_penalties);
-            else if (b->maxlen <= 256)
-                hipLaunchKernelGGL(nw_unit_kernel<4>, g, t, 0, h->stream, b->d_planes, b->d_lens, (long)b->n, b->w4, d_penalties);
-            else if (b->maxlen <= 384)
-                hipLaunchKernelGGL(nw_unit_kernel<6>, g, t, 0, h->stream, b->d_planes, b->d_lens, (long)b->n, b->w4, d_penalties);
+            if (!h->nw_banded) {
+                if (b->maxlen <= 128)
+                    hipLaunchKernelGGL(nw_unit_kernel<2>, g, t, 0, h->stream, b->d_planes, b->d_lens, (long)b->n, b->w4, d_penalties);
+                else if (b->maxlen <= 256)
+                    hipLaunchKernelGGL(nw_unit_kernel<4>, g, t, 0, h->stream, b->d_planes, b->d_lens, (long)b->n, b->w4, d_penalties);
+                else if (b->maxlen <= 384)
+                    hipLaunchKernelGGL(nw_unit_kernel<6>, g, t, 0, h->stream, b->d_planes, b->d_lens, (long)b->n, b->w4, d_penalties);
+                else
+                    hipLaunchKernelGGL(nw_unit_kernel<8>, g, t, 0, h->stream, b->d_planes, b->d_lens, (long)b->n, b->w4, d_penalties);
+            } else if (b->w4 == 1)
+                hipLaunchKernelGGL(nw_banded_kernel<4>, g, t, 0, h->stream, b->d_planes, b->d_lens, (long)b->n, b->w4, d_penalties);
+            else if (b->w4 == 2)
+                hipLaunchKernelGGL(nw_banded_kernel<8>, g, t, 0, h->stream, b->d_planes, b->d_lens, (long)b->n, b->w4, d_penalties);
+            else if (b->w4 == 3)
+                hipLaunchKernelGGL(nw_banded_kernel<12>, g, t, 0, h->stream, b->d_planes, b->d_lens, (long)b->n, b->w4, d_penalties);
             else
-                hipLaunchKernelGGL(nw_unit_kernel<8>, g, t, 0, h->stream, b->d_planes, b->d_lens, (long)b->n, b->w4, d_penalties);
+                hipLaunchKernelGGL(nw_banded_kernel<16>, g, t, 0, h->stream, b->d_planes, b->d_lens, (long)b->n, b->w4, d_penalties);
         } else {
             launch_nw_affine(h->stream, b->d_planes, b->d_lens, b->n, b->w4, b->maxlen, p->x, p->o, p->e, d_penalties);
         }
