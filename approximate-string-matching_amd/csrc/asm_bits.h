@@ -62,6 +62,15 @@ ASM_DEV int v_first_one(V128 v) {
 // utils.h:187-191
 ASM_DEV int v_first_zero(V128 v) { return v_first_one(v_not(v)); }
 
+// first_one(l >> fz) for fz = first_zero(l), without the second shift: l has ones exactly below bit fz and a zero
+// at fz, so l + 1 clears that run and sets bit fz, and (l + 1) & l keeps only the ones above fz.  128 when none.
+ASM_DEV int v_next_one_after_zero_run(V128 l, int fz) {
+    const u64 lo1 = l.lo + 1ull;
+    const u64 hi1 = l.hi + (lo1 == 0ull ? 1ull : 0ull);
+    const int p = v_first_one(v_make(lo1 & l.lo, hi1 & l.hi));
+    return p == 128 ? 128 : p - fz;
+}
+
 ASM_DEV int v_popcount(V128 v) { return __popcll(v.lo) + __popcll(v.hi); }
 
 // utils.h:263-270: ones in [from,to); 0 when from+128-to falls outside [0,127] or from outside [0,127].

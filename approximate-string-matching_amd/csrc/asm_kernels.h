@@ -209,7 +209,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_kernel(const uint4* __restri
                 nsw[j] = d < 0 ? -d : d;
                 const V128 l = v_toward0(lf_[j], start_col);
                 const int fz = v_first_zero(l);
-                const int nx = v_first_one(v_toward0(l, fz));
+                const int nx = v_next_one_after_zero_run(l, fz);
                 sp[j] = start_col + fz;
                 len[j] = nx;
                 if (start_col + fz + nx > dst[j]) {
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_kernel(const uint4* __restri
             const int lane = j - K;
             if (lane != best && !(sp[j] + fwd_col(lane, best) > best_sp)) {
                 const int endp = sp[j] + len[j];
-                const int inter = sw[j] + v_pop_between(lo_[j], cur_col + fwd_col(cur_lane, lane), endp);
+                const int inter = sw[j] + nh[j]; /* the same range loop 1 counted: [cur_col + fwd, sp + len) */
                 const int tail = x * v_pop_between(best_vec, fwd_col(lane, best) + endp, best_sp);
                 const int total = inter + lane_penalty(lane, best, o, e) + (tail > 0 ? tail : 0);
                 if (total <= small_total && inter <= small_inter) {
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_persist_kernel(const uint4* 
                     nsw[j] = d < 0 ? -d : d;
                     const V128 l = v_toward0(lf_[j], start_col);
                     const int fz = v_first_zero(l);
-                    const int nx = v_first_one(v_toward0(l, fz));
+                    const int nx = v_next_one_after_zero_run(l, fz);
                     sp[j] = start_col + fz;
                     len[j] = nx;
                     if (start_col + fz + nx > dst[j]) {
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_persist_kernel(const uint4* 
                     const int lane = j - K;
                     if (lane != best && !(sp[j] + fwd_col(lane, best) > best_sp)) {
                         const int endp = sp[j] + len[j];
-                        const int inter = sw[j] + v_pop_between(lo_[j], cur_col + fwd_col(cur_lane, lane), endp);
+                        const int inter = sw[j] + nh[j]; /* the same range loop 1 counted: [cur_col + fwd, sp + len) */
                         const int tail = x * v_pop_between(best_vec, fwd_col(lane, best) + endp, best_sp);
                         const int total = inter + lane_penalty(lane, best, o, e) + (tail > 0 ? tail : 0);
                         if (total <= small_total && inter <= small_inter) {
