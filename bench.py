@@ -26,6 +26,19 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md §Chip-level parameters)
 
 
+def pmc_traffic(kernel, pairs):
+    """HBM bytes per launch of `kernel` from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, collected offline with
+    tools/pmc_traffic.sh in separate rocprofv3 --pmc passes and committed as profiles/r01_pmc_traffic.json), scaled
+    to this launch's pair count.  None when no measurement is on file."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        return d["kernels"][kernel]["traffic_bytes"] * pairs / d["pairs"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def algorithmic_bytes(m, n, aligners=1):
     """2-bit packed inputs read once + one int32 penalty per aligner, per pair."""
     return (np.ceil(2 * m / 8) + np.ceil(2 * n / 8) + 4 * aligners).sum()
@@ -162,7 +175,7 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": pmc_traffic(dom, n),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": kernel_ms[dom],
                 "note": "integer-VALU-bound path (SURVEY.md F7): see DESIGN.md §5 for the VALU-side ceiling",
