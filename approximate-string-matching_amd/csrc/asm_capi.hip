@@ -263,6 +263,32 @@ int asm_batch_pack_async(asm_handle* h, asm_batch* b) {
     return ASM_OK;
 }
 
+/* ASM_GREEDY_SEQUENTIAL: derive the stale buffer tails on the device (asm_tails.h) from the clean-mode planes that
+ * the first pack produced, then pack again so that granule 0 carries them. */
+static int batch_resolve_tails(asm_handle* h, asm_batch* b) {
+    if (b->n == 0) return ASM_OK;
+    const long nchunks = (b->n + TAIL_CHUNK - 1) / TAIL_CHUNK;
+    uint8_t *d_last = nullptr, *d_carry = nullptr;
+    HIPCHK(h, hipMalloc((void**)&b->d_tails, sizeof(uint4) * 4 * (size_t)b->n));
+    HIPCHK(h, hipMalloc((void**)&d_last, (size_t)nchunks * 256));
+    HIPCHK(h, hipMalloc((void**)&d_carry, (size_t)nchunks * 256));
+    uint4* tails = b->d_tails;
+    b->d_tails = nullptr; /* the planes read below must be the clean ones; pack has already run without tails */
+    hipLaunchKernelGGL(tails_chunk_kernel, dim3((unsigned)nchunks), dim3(256), 0, h->stream, b->d_planes, b->d_lens,
+                       (long)b->n, b->w4, d_last);
+    hipLaunchKernelGGL(tails_carry_kernel, dim3(1), dim3(256), 0, h->stream, d_last, d_carry, nchunks);
+    hipLaunchKernelGGL(tails_emit_kernel, dim3((unsigned)nchunks), dim3(256), 0, h->stream, b->d_planes, b->d_lens,
+                       (long)b->n, b->w4, d_carry, tails);
+    hipError_t e = hipGetLastError();
+    b->d_tails = tails;
+    int rc = e == hipSuccess ? asm_batch_pack_async(h, b) : fail(h, ASM_ENODEVICE, hipGetErrorString(e));
+    hipError_t e2 = hipStreamSynchronize(h->stream);
+    (void)hipFree(d_last);
+    (void)hipFree(d_carry);
+    if (!rc && e2 != hipSuccess) rc = fail(h, ASM_ENODEVICE, hipGetErrorString(e2));
+    return rc;
+}
+
 int asm_batch_upload(asm_handle* h, int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
                      const uint32_t* ref_off, int greedy_mode, asm_batch** out) {
     if (!h || !out || n < 0 || !read_off || !ref_off || (n > 0 && (!reads || !refs)))
@@ -303,17 +329,12 @@ int asm_batch_upload(asm_handle* h, int64_t n, const char* reads, const uint32_t
         TRY(hipMemcpyAsync(b->d_refs, refs, b->refs_bytes, hipMemcpyHostToDevice, h->stream));
         TRY(hipMemcpyAsync(b->d_read_off, read_off, sizeof(uint32_t) * (size_t)(n + 1), hipMemcpyHostToDevice, h->stream));
         TRY(hipMemcpyAsync(b->d_ref_off, ref_off, sizeof(uint32_t) * (size_t)(n + 1), hipMemcpyHostToDevice, h->stream));
-        if (greedy_mode == ASM_GREEDY_SEQUENTIAL && n > 0) {
-            std::vector<uint32_t> tails((size_t)16 * (size_t)n);
-            asm_resolve_tails_host(n, reads, read_off, refs, ref_off, tails.data());
-            TRY(hipMalloc((void**)&b->d_tails, sizeof(uint4) * 4 * (size_t)n));
-            TRY(hipMemcpyAsync(b->d_tails, tails.data(), sizeof(uint4) * 4 * (size_t)n, hipMemcpyHostToDevice, h->stream));
-            TRY(hipStreamSynchronize(h->stream)); /* `tails` goes out of scope */
-        }
 #undef TRY
         rc = batch_alloc_packed(h, b);
         if (rc) break;
         rc = asm_batch_pack_async(h, b);
+        if (rc) break;
+        if (greedy_mode == ASM_GREEDY_SEQUENTIAL) rc = batch_resolve_tails(h, b);
         if (rc) break;
         if (hipStreamSynchronize(h->stream) != hipSuccess) {
             rc = fail(h, ASM_ENODEVICE, "asm_batch_upload: stream synchronize failed");
@@ -333,9 +354,8 @@ int asm_batch_generate(asm_handle* h, const asm_gen_config* cfg, int64_t first, 
     if (!h || !out || n < 0 || first < 0) return fail(h, ASM_EINVAL, "asm_batch_generate: bad arguments");
     int rc = check_gen(cfg);
     if (rc) return fail(h, rc, g_err);
-    if (greedy_mode != ASM_GREEDY_CLEAN)
-        return fail(h, ASM_EUNSUPPORTED,
-                    "asm_batch_generate: only ASM_GREEDY_CLEAN (sequential tails are resolved by asm_batch_upload)");
+    if (greedy_mode != ASM_GREEDY_CLEAN && greedy_mode != ASM_GREEDY_SEQUENTIAL)
+        return fail(h, ASM_EINVAL, "asm_batch_generate: unknown greedy_mode");
     *out = nullptr;
     HIPCHK(h, hipSetDevice(h->device));
     asm_batch* b = new asm_batch;
@@ -404,6 +424,8 @@ int asm_batch_generate(asm_handle* h, const asm_gen_config* cfg, int64_t first, 
         rc = batch_alloc_packed(h, b);
         if (rc) break;
         rc = asm_batch_pack_async(h, b);
+        if (rc) break;
+        if (greedy_mode == ASM_GREEDY_SEQUENTIAL) rc = batch_resolve_tails(h, b);
         if (rc) break;
         if (hipStreamSynchronize(h->stream) != hipSuccess) {
             rc = fail(h, ASM_ENODEVICE, "asm_batch_generate: stream synchronize failed");

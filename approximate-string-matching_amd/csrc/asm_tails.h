@@ -1,42 +1,140 @@
-// Stale-tail model of the reference's Greedy buffers — host pre-pass, sequential mode only.
+// Stale-tail resolver for ASM_GREEDY_SEQUENTIAL — device side.
 //
-// hurdle_matrix keeps two persistent 128-byte buffers (GASMA/hurdle_matrix.h:136-137).  reset() copies only
-// the first m / n characters in (:630-631) and sse3_convert2bit1 then permutes each whole buffer in place
-// (GASMA/bit_convert.cpp:265-330: after[q] = before[8*(q mod 16) + P[q div 16]], P = {0,2,1,3,4,6,5,7}).
-// So the bytes beyond a string's end that the conversion of pair t sees are scrambled characters of earlier
-// pairs.  This pass replays that chain in batch order (it is a strict sequential dependency through the
-// buffers, carried before the batch is sharded) and emits, per pair, the bit planes of those tail bytes only;
-// the pack kernel ORs them into granule 0.  Initial buffer content is pinned to zero (the reference's is
+// hurdle_matrix keeps two persistent 128-byte buffers (GASMA/hurdle_matrix.h:136-137).  reset() copies only the
+// first m / n characters in (:630-631) and sse3_convert2bit1 then permutes each whole buffer in place
+// (GASMA/bit_convert.cpp:265-330: after[q] = before[SRC[q]], SRC[q] = 8*(q mod 16) + P[q div 16], P = {0,2,1,3,4,6,5,7}).
+// So the bytes beyond a string's end that the conversion of pair t sees are scrambled characters of earlier pairs.
+//
+// Parallel formulation.  Follow one buffer slot forward in time: a byte sitting in slot s when pair t is converted
+// sits in slot SRC^-1[s] when pair t+1 is converted — unless pair t+1's string is long enough to overwrite it.  So
+// each of the 128 slots of a side starts a *trajectory* s, SRC^-1[s], SRC^-1[SRC^-1[s]], ... that carries "the code
+// of the last character written on this trajectory".  SRC has order 10 (cycles of length 1, 2, 5, 10), so after any
+// multiple of 10 pairs every trajectory is back in its starting slot; with chunks of 2560 pairs the trajectories of
+// consecutive chunks line up by thread index and the carried state is just a 2-bit code:
+//   pass 1  tails_chunk_kernel : per chunk and trajectory, the code of the last write inside the chunk (or none)
+//   pass 2  tails_carry_kernel : exclusive "last write wins" prefix over chunks (initial buffers = NUL, code 00)
+//   pass 3  tails_emit_kernel  : replay each chunk from its carry-in; wherever the trajectory's slot lies beyond the
+//                                pair's string, that pair's conversion sees the carried code: set the bits in `tails`
+// Character codes are read from the clean-mode bit planes (bit q of a plane <-> character q), so the passes touch no
+// ASCII.  The pack kernel ORs `tails` into granule 0.  Initial buffer content is pinned to zero (the reference's is
 // indeterminate heap memory).
 #pragma once
+#include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <string.h>
 
-#include <vector>
+#define TAIL_CHUNK 2560 /* pairs per chunk: a multiple of 10 (the order of SRC) and of TAIL_SUB */
+#define TAIL_SUB 256    /* pairs whose tail planes are accumulated in LDS at a time */
+#define TAIL_BATCH 8    /* pairs whose plane words are fetched ahead */
+#define TAIL_NONE 0xFFu
 
-static inline void asm_resolve_tails_host(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
-                                          const uint32_t* ref_off, uint32_t* tails /* [4][n][4] */) {
-    static const int P[8] = {0, 2, 1, 3, 4, 6, 5, 7};
-    int src[128];
-    for (int q = 0; q < 128; q++) src[q] = 8 * (q & 15) + P[q >> 4];
-    uint8_t buf[2][128], tmp[128];
-    memset(buf, 0, sizeof(buf));
-    for (int64_t i = 0; i < n; i++) {
-        const char* str[2] = {reads + read_off[i], refs + ref_off[i]};
-        int len[2] = {(int)(read_off[i + 1] - read_off[i]), (int)(ref_off[i + 1] - ref_off[i])};
-        for (int s = 0; s < 2; s++) {
-            if (len[s] > 128) len[s] = 128;
-            memcpy(buf[s], str[s], (size_t)len[s]);
-            uint32_t p0[4] = {0, 0, 0, 0}, p1[4] = {0, 0, 0, 0};
-            for (int q = len[s]; q < 128; q++) {
-                const uint8_t c = buf[s][q];
-                if (c == 'C' || c == 'T') p0[q >> 5] |= 1u << (q & 31);
-                if (c == 'G' || c == 'T') p1[q >> 5] |= 1u << (q & 31);
+// SRC^-1: SRC[q] = 8*(q & 15) + P[q >> 4] and P is an involution, so q = (P[y & 7] << 4) | (y >> 3).
+__device__ __forceinline__ int tail_src_inv(int y) {
+    const int v = y & 7;
+    const int low2 = v & 3;
+    const int pv = (low2 == 1 || low2 == 2) ? (v ^ 3) : v; /* P swaps 1<->2 and 5<->6 */
+    return (pv << 4) | (y >> 3);
+}
+
+struct TailLane {
+    int side, slot;
+    const uint32_t *p0, *p1; /* this side's two bit planes, granule 0, viewed as dwords (4 per pair) */
+};
+
+__device__ __forceinline__ TailLane tail_lane_init(const uint4* planes, long n, int w4) {
+    TailLane tl;
+    tl.side = threadIdx.x >> 7;
+    tl.slot = threadIdx.x & 127;
+    tl.p0 = reinterpret_cast<const uint32_t*>(planes + ((long)(2 * tl.side) * w4) * n);
+    tl.p1 = reinterpret_cast<const uint32_t*>(planes + ((long)(2 * tl.side + 1) * w4) * n);
+    return tl;
+}
+
+// One batch of up to TAIL_BATCH pairs starting at t: all loads first (the slot sequence is data independent), then
+// the sequential replay.  EMIT=false: only track the carried code.  EMIT=true: also set tail bits in LDS.
+template <bool EMIT>
+__device__ __forceinline__ void tail_batch(TailLane& tl, const uint32_t* __restrict__ lens, long t, int cnt,
+                                           uint32_t& code, uint32_t* s_tail, long sub_base) {
+    int slots[TAIL_BATCH];
+    uint32_t L[TAIL_BATCH], w0[TAIL_BATCH], w1[TAIL_BATCH];
+    int s = tl.slot;
+#pragma unroll
+    for (int i = 0; i < TAIL_BATCH; i++) {
+        slots[i] = s;
+        s = tail_src_inv(s);
+        const long tt = t + (i < cnt ? i : cnt - 1);
+        const uint32_t ln = lens[tt];
+        uint32_t len = tl.side ? (ln >> 16) : (ln & 0xffffu);
+        L[i] = len > 128u ? 128u : len; /* hurdle_matrix.h:626-627 */
+        w0[i] = tl.p0[tt * 4 + (slots[i] >> 5)];
+        w1[i] = tl.p1[tt * 4 + (slots[i] >> 5)];
+    }
+#pragma unroll
+    for (int i = 0; i < TAIL_BATCH; i++) {
+        if (i < cnt) {
+            const int q = slots[i];
+            if ((uint32_t)q < L[i]) {
+                code = ((w0[i] >> (q & 31)) & 1u) | (((w1[i] >> (q & 31)) & 1u) << 1); /* this pair overwrites the slot */
+            } else if (EMIT && code != 0u) {
+                /* slot q lies beyond pair (t+i)'s string: its conversion sees the carried character */
+                uint32_t* row = s_tail + ((size_t)(t + i - sub_base) * 4 + 2 * tl.side) * 4;
+                if (code & 1u) atomicOr(&row[q >> 5], 1u << (q & 31));
+                if (code & 2u) atomicOr(&row[4 + (q >> 5)], 1u << (q & 31));
             }
-            memcpy(tails + ((size_t)(2 * s + 0) * n + i) * 4, p0, 16);
-            memcpy(tails + ((size_t)(2 * s + 1) * n + i) * 4, p1, 16);
-            for (int q = 0; q < 128; q++) tmp[q] = buf[s][src[q]];
-            memcpy(buf[s], tmp, 128);
+            tl.slot = tail_src_inv(q);
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void tails_chunk_kernel(const uint4* __restrict__ planes,
+                                                          const uint32_t* __restrict__ lens, long n, int w4,
+                                                          uint8_t* __restrict__ chunk_last /* [nchunks][256] */) {
+    TailLane tl = tail_lane_init(planes, n, w4);
+    const long t0 = (long)blockIdx.x * TAIL_CHUNK;
+    const long t1 = t0 + TAIL_CHUNK < n ? t0 + TAIL_CHUNK : n;
+    uint32_t code = TAIL_NONE;
+    for (long t = t0; t < t1; t += TAIL_BATCH) {
+        const int cnt = (t1 - t) < TAIL_BATCH ? (int)(t1 - t) : TAIL_BATCH;
+        tail_batch<false>(tl, lens, t, cnt, code, nullptr, 0);
+    }
+    chunk_last[(long)blockIdx.x * 256 + threadIdx.x] = (uint8_t)code;
+}
+
+__global__ __launch_bounds__(256) void tails_carry_kernel(const uint8_t* __restrict__ chunk_last,
+                                                          uint8_t* __restrict__ carry_in, long nchunks) {
+    uint32_t cur = 0u; /* buffers start as NUL bytes: code 00 */
+    for (long c = 0; c < nchunks; c++) {
+        const uint32_t s = chunk_last[c * 256 + threadIdx.x];
+        carry_in[c * 256 + threadIdx.x] = (uint8_t)cur;
+        if (s != TAIL_NONE) cur = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void tails_emit_kernel(const uint4* __restrict__ planes,
+                                                         const uint32_t* __restrict__ lens, long n, int w4,
+                                                         const uint8_t* __restrict__ carry_in,
+                                                         uint4* __restrict__ tails /* [4][n] */) {
+    __shared__ uint32_t s_tail[TAIL_SUB * 16]; /* [pair][plane A0,A1,B0,B1][4 dwords] */
+    TailLane tl = tail_lane_init(planes, n, w4);
+    const long t0 = (long)blockIdx.x * TAIL_CHUNK;
+    const long t1 = t0 + TAIL_CHUNK < n ? t0 + TAIL_CHUNK : n;
+    uint32_t code = carry_in[(long)blockIdx.x * 256 + threadIdx.x];
+    for (long sb = t0; sb < t1; sb += TAIL_SUB) {
+        const long se = sb + TAIL_SUB < t1 ? sb + TAIL_SUB : t1;
+        for (int i = threadIdx.x; i < TAIL_SUB * 16; i += 256) s_tail[i] = 0u;
+        __syncthreads();
+        for (long t = sb; t < se; t += TAIL_BATCH) {
+            const int cnt = (se - t) < TAIL_BATCH ? (int)(se - t) : TAIL_BATCH;
+            tail_batch<true>(tl, lens, t, cnt, code, s_tail, sb);
+        }
+        __syncthreads();
+        // flush: thread i owns pair sb+i
+        const long t = sb + threadIdx.x;
+        if (t < se) {
+            const uint32_t* row = s_tail + (size_t)threadIdx.x * 16;
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+                tails[(long)p * n + t] = make_uint4(row[4 * p], row[4 * p + 1], row[4 * p + 2], row[4 * p + 3]);
+        }
+        __syncthreads();
     }
 }

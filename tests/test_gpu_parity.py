@@ -38,6 +38,25 @@ def test_sequential_mode_matches_reference_order_dependence(asm, engine, oracle)
     _check("nw", engine.align(batch, asm.NW, params), oracle.nw(hb), hb)
 
 
+@pytest.mark.parametrize("wl,n,k", [("C5", 12000, 3), ("C1", 10000, 3), ("C4", 8000, 2)])
+def test_sequential_mode_device_resolver(asm, engine, oracle, wl, n, k):
+    """The stale-tail chain is resolved on the GPU (csrc/asm_tails.h: three passes over 2560-pair chunks), both for
+    uploaded batches and for batches generated on the device; mixed lengths make long carry chains."""
+    cfg, _, _ = asm.workload(wl)
+    hb = asm.generate_pairs(cfg, 17, n)
+    want = oracle.greedy(hb, k=k, mode=0)
+    params = asm.Params.default(k=k)
+    _check("upload", engine.align(engine.upload(hb, asm.GREEDY_SEQUENTIAL), asm.GREEDY, params), want, hb)
+    _check("generate", engine.align(engine.generate(cfg, 17, n, asm.GREEDY_SEQUENTIAL), asm.GREEDY, params), want, hb)
+
+
+def test_sequential_mode_ragged_lengths(asm, engine, oracle):
+    hb = random_ragged_batch(asm, 21, 6000, 0, 200)
+    want = oracle.greedy(hb, k=3, mode=0)
+    got = engine.align(engine.upload(hb, asm.GREEDY_SEQUENTIAL), asm.GREEDY, asm.Params.default(k=3))
+    _check("ragged-seq", got, want, hb)
+
+
 def test_c3_wide_band_150bp(asm, engine, oracle):
     """C3: 150 bp, err .20, k=30 — workgroup-per-pair kernels; Greedy sees the first 128 bases (F6)."""
     cfg, _, params = asm.workload("C3")
