@@ -14,6 +14,7 @@
 #include "../../include/asm_mi355x.h"
 #include "asm_kernels.h"
 #include "asm_wide.h"
+#include "asm_wave.h"
 #include "asm_tails.h"
 
 struct asm_handle {
@@ -25,6 +26,7 @@ struct asm_handle {
     bool persist = true;                  /* Greedy: lane-refilling persistent kernel (ASM_PERSIST=0 disables) */
     bool persist_leap = false;            /* LEAP: the plain one-pair-per-thread kernel is faster at 1e6 pairs (ASM_PERSIST_LEAP=1) */
     int refill_greedy = 8, refill_leap = 16; /* lanes that must be idle before a wave refills (tunable by env) */
+    bool wave_kernels = true;             /* wave-per-pair kernels for 6 <= k <= 31 (ASM_WAVE=0: workgroup-per-pair LDS kernels) */
     bool nw_banded = true;                /* banded bit-parallel NW with in-kernel full-height recompute (ASM_NW_BANDED=0) */
     unsigned long long* d_work = nullptr; /* work-queue heads for the persistent kernels */
     unsigned work_slot = 0;
@@ -142,6 +144,7 @@ int asm_create(asm_handle** out, int device) {
     const char* env = getenv("ASM_PERSIST");
     h->persist = !(env && env[0] == '0');
     if ((env = getenv("ASM_PERSIST_LEAP"))) h->persist_leap = env[0] != '0';
+    if ((env = getenv("ASM_WAVE"))) h->wave_kernels = env[0] != '0';
     if ((env = getenv("ASM_NW_BANDED"))) h->nw_banded = env[0] != '0';
     if ((env = getenv("ASM_REFILL_GREEDY"))) h->refill_greedy = atoi(env);
     if ((env = getenv("ASM_REFILL_LEAP"))) h->refill_leap = atoi(env);
@@ -511,7 +514,13 @@ int asm_align_batch_async(asm_handle* h, const asm_batch* b, int aligner, const 
             case 3: HIPCHK(h, launch_greedy<3>(h, b, ga, d_penalties)); break;
             case 4: HIPCHK(h, launch_greedy<4>(h, b, ga, d_penalties)); break;
             case 5: HIPCHK(h, launch_greedy<5>(h, b, ga, d_penalties)); break;
-            default: launch_greedy_wide(h->stream, b->d_planes, b->d_lens, b->n, b->w4, p->k, ga, d_penalties); break;
+            default:
+                if (p->k <= ASM_WAVE_MAX_K && h->wave_kernels && (long)p->o + 62L * p->e < 16000L)
+                    launch_wave_per_pair(h->stream, greedy_wave_kernel, b->n, h->num_cus, (const uint4*)b->d_planes,
+                                         (const uint32_t*)b->d_lens, (long)b->n, b->w4, (int)p->k, ga, d_penalties);
+                else
+                    launch_greedy_wide(h->stream, b->d_planes, b->d_lens, b->n, b->w4, p->k, ga, d_penalties);
+                break;
         }
     } else if (aligner == ASM_LEAP) {
         if (unit && p->k >= 1 && p->k <= 5 && b->maxlen <= 256) {
@@ -522,6 +531,17 @@ int asm_align_batch_async(asm_handle* h, const asm_batch* b, int aligner, const 
                 case 4: HIPCHK(h, launch_leap_unit<4>(h, b, d_penalties)); break;
                 default: HIPCHK(h, launch_leap_unit<5>(h, b, d_penalties)); break;
             }
+        } else if (unit && p->k <= ASM_WAVE_MAX_K && h->wave_kernels) {
+#define LEAP_WAVE(W)                                                                                               \
+    launch_wave_per_pair(h->stream, leap_wave_kernel<W>, b->n, h->num_cus, (const uint4*)b->d_planes,              \
+                         (const uint32_t*)b->d_lens, (long)b->n, b->w4, (int)p->k, d_penalties)
+            switch (b->w4) {
+                case 1: LEAP_WAVE(2); break;
+                case 2: LEAP_WAVE(4); break;
+                case 3: LEAP_WAVE(6); break;
+                default: LEAP_WAVE(8); break;
+            }
+#undef LEAP_WAVE
         } else {
             launch_leap_wide(h->stream, b->d_planes, b->d_lens, b->n, b->w4, p->k, p->x, p->o, p->e, d_penalties);
         }

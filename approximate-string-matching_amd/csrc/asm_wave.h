@@ -1,0 +1,245 @@
+// Wide-band kernels, ONE WAVEFRONT PER READ PAIR (k <= 31: the 2k+1 <= 63 band lanes map onto the 64 lanes of a
+// wave; at the benchmark's k = 30 that is 61 of 64 lanes busy).  Neighbouring band lanes talk through DPP wave
+// shifts, the wave agrees on "best lane" through DPP max-reductions on order-preserving integer keys, and
+// wave-uniform decisions (termination, the chosen lane) live in scalar registers via __ballot / v_readlane.
+// No LDS, no barriers — the workgroup-per-pair kernels of asm_wide.h remain for k > 31 and for general LEAP penalties.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "asm_bits.h"
+#include "asm_kernels.h"
+
+#define ASM_WAVE_MAX_K 31
+
+// DPP controls (gfx9 family): lane i reads lane i-1 / i+1 of the whole wave; lanes with no source keep `old`.
+#define DPP_WAVE_SHL1 0x130 /* lane i <- lane i+1 */
+#define DPP_WAVE_SHR1 0x138 /* lane i <- lane i-1 */
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_BCAST15 0x142
+#define DPP_BCAST31 0x143
+
+ASM_DEV int wave_from_below(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, DPP_WAVE_SHR1, 0xf, 0xf, false); }
+ASM_DEV int wave_from_above(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, DPP_WAVE_SHL1, 0xf, 0xf, false); }
+
+// max over the 64 lanes, returned wave-uniform (scan within rows of 16, then row broadcasts; identity 0)
+ASM_DEV unsigned wave_max_u32(unsigned v) {
+#define STEP(ctrl, rmask)                                                                              \
+    {                                                                                                  \
+        const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, false);  \
+        v = o > v ? o : v;                                                                             \
+    }
+    STEP(DPP_ROW_SHR(1), 0xf)
+    STEP(DPP_ROW_SHR(2), 0xf)
+    STEP(DPP_ROW_SHR(4), 0xf)
+    STEP(DPP_ROW_SHR(8), 0xf)
+    STEP(DPP_BCAST15, 0xa)
+    STEP(DPP_BCAST31, 0xc)
+#undef STEP
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+ASM_DEV int lane_read(int v, int lane /* wave-uniform */) {
+    return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(lane));
+}
+
+// --------------------------------------------------------------------------------------------------------
+// LEAP, unit penalties, wave per pair.  Same recurrence as leap_unit_kernel (LV::run, LV_BAG.cpp:127-245);
+// lane t of the wave is LEAP lane l = t + 1 (d = t - k), generation e-1 lives in three VGPRs per lane.
+// --------------------------------------------------------------------------------------------------------
+template <int W64>
+__global__ __launch_bounds__(ASM_BLOCK) void leap_wave_kernel(const uint4* __restrict__ planes,
+                                                              const uint32_t* __restrict__ lens, long n, int w4,
+                                                              int k, int32_t* __restrict__ out) {
+    const int t = threadIdx.x & 63;
+    const long wave0 = __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    const int nl = 2 * k + 1;
+    const bool active = t < nl;
+    const int d = t - k;
+    const int diff = d < 0 ? -d : d;
+    const int top = d >= 0 ? 1 : 0, bot = d <= 0 ? 1 : 0;
+    for (long i = wave0; i < n; i += nwaves) {
+        const uint32_t ln = lens[i];
+        const int m = (int)(ln & 0xffffu), nn = (int)(ln >> 16);
+        const int len = m > nn ? m : nn; /* benchmark_utils.h:162 */
+        VW<W64> A0, A1, B0, B1;
+        load_planes<W64>(planes, n, w4, i, A0, A1, B0, B1);
+        const VW<W64> VA = vw_low_ones<W64>(m), VB = vw_low_ones<W64>(nn);
+        VW<W64> mask = leap_lane_mask<W64>(A0, A1, B0, B1, VA, VB, active ? d : 0);
+        int en = -2, ip = -2, dp = -2, result = -1;
+        if (t == k) { /* e = 0: main diagonal only (LV_BAG.cpp:102-104,131-147) */
+            int e0 = vw_next_one<W64>(mask, 0);
+            en = e0 > len ? len : e0;
+        }
+        if (__ballot(t == k && en == len) != 0ull) {
+            result = 0;
+        } else {
+            for (int e = 1; e <= ASM_LEAP_AF_THRESHOLD; e++) {
+                const int e_up = wave_from_below(en, -2), i_up = wave_from_below(ip, -2);
+                const int e_dn = wave_from_above(en, -2), d_dn = wave_from_above(dp, -2);
+                int inew = -2, dnew = -2;
+                if (e_up >= 0 && e_up > i_up)
+                    inew = e_up + top; /* LV_BAG.cpp:166-167 */
+                else if (i_up >= 0)
+                    inew = i_up + top; /* :172-176 */
+                if (e_dn >= 0 && e_dn > d_dn)
+                    dnew = e_dn + bot; /* :179-180 */
+                else if (d_dn >= 0)
+                    dnew = d_dn + bot; /* :181-182 */
+                int st = en >= 0 ? en + 1 : -2; /* :186-187 */
+                st = inew > st ? inew : st;
+                st = dnew > st ? dnew : st;
+                int enew = -2;
+                bool pass = false;
+                if (active && st >= 0) {
+                    const int from = st > len ? len : st;
+                    int r = vw_next_one<W64>(mask, from); /* count_ID_length, :9-23 */
+                    r = r > len ? len : r;
+                    enew = st > len ? st : r;
+                    pass = enew == len && e + diff <= ASM_LEAP_AF_THRESHOLD; /* :220-238 */
+                }
+                /* lanes outside the band stay at -2 so that they look like the reference's sentinel lanes */
+                en = active ? enew : -2, ip = active ? inew : -2, dp = active ? dnew : -2;
+                if (__ballot(pass) != 0ull) {
+                    result = e; /* final_ED (LV_BAG.cpp:228,356-358) */
+                    break;
+                }
+            }
+        }
+        if (t == 0) out[i] = result;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------
+// Greedy, wave per pair.  Same step structure as greedy_kernel<K> (hurdle_matrix.h:285-434,568-597); lane t of the
+// wave is band lane t - k.
+// --------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ASM_BLOCK) void greedy_wave_kernel(const uint4* __restrict__ planes,
+                                                                const uint32_t* __restrict__ lens, long n, int w4,
+                                                                int k, GreedyArgs args, int32_t* __restrict__ out) {
+    const int t = threadIdx.x & 63;
+    const long wave0 = __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    const int nl = 2 * k + 1;
+    const bool active = t < nl;
+    const int lane = t - k;
+    const int x = args.x, o = args.o, e = args.e;
+    for (long i = wave0; i < n; i += nwaves) {
+        const V128 A0 = v_from_uint4(planes[((long)0 * w4) * n + i]);
+        const V128 A1 = v_from_uint4(planes[((long)1 * w4) * n + i]);
+        const V128 B0 = v_from_uint4(planes[((long)2 * w4) * n + i]);
+        const V128 B1 = v_from_uint4(planes[((long)3 * w4) * n + i]);
+        const uint32_t ln = lens[i];
+        int m = (int)(ln & 0xffffu), nn = (int)(ln >> 16);
+        m = m > 128 ? 128 : m; /* hurdle_matrix.h:626-627 */
+        nn = nn > 128 ? 128 : nn;
+        const int dest_lane = nn - m;
+        const V128 lo_ = greedy_lane_vector(A0, A1, B0, B1, lane);
+        const V128 lf_ = v_flip_short_hurdles1(lo_);
+        const int dst = lane_destination(m, nn, lane);
+        int sp = -1, len = 0, nsw = 128;
+        int cur_lane = 0, cur_col = 0, cost = 0;
+        for (int guard = 0; guard < 4 * 128; guard++) {
+            // ---- _update_highway_list, one band lane per wave lane ----
+            bool reach = false;
+            int sw = 0, nh = 0;
+            const int start_col = cur_col + fwd_col(cur_lane, lane);
+            if (active) {
+                if (sp < start_col) {
+                    const int dd = lane - cur_lane;
+                    nsw = dd < 0 ? -dd : dd;
+                    const V128 l = v_toward0(lf_, start_col);
+                    const int fz = v_first_zero(l);
+                    const int nx = v_next_one_after_zero_run(l, fz);
+                    sp = start_col + fz;
+                    len = nx;
+                    if (start_col + fz + nx > dst) {
+                        const int c = dst - (start_col + fz);
+                        len = c > 0 ? c : 0;
+                        reach = true;
+                    }
+                }
+                sw = lane_penalty(cur_lane, lane, o, e);
+                nh = v_pop_between(lo_, start_col, sp + len);
+            }
+            const bool reaching = __ballot(reach) != 0ull;
+            const int hc = x * nh;
+            double heur = greedy_significance(args, len, nh, nsw);
+            int leap = -sw;
+            if (reaching) {
+                const int fsw = lane_penalty(lane, dest_lane, o, e);
+                heur = (double)(-sw - hc - fsw - x * (dst - sp - len));
+                leap -= fsw;
+            }
+            // arg-max of (heur, leap), first lane wins exact ties (hurdle_matrix.h:345-351): order-preserving integer
+            // keys and three 32-bit wave max-reductions
+            heur = heur + 0.0; /* -0.0 -> +0.0 so that equal values have equal keys */
+            const unsigned long long hb = (unsigned long long)__double_as_longlong(heur);
+            const unsigned long long key = (hb >> 63) ? ~hb : (hb | 0x8000000000000000ull);
+            unsigned khi = active ? (unsigned)(key >> 32) : 0u;
+            const unsigned mhi = wave_max_u32(khi);
+            bool cand = active && khi == mhi;
+            const unsigned klo = cand ? (unsigned)key : 0u;
+            const unsigned mlo = wave_max_u32(klo);
+            cand = cand && klo == mlo;
+            const unsigned k3 = cand ? ((((unsigned)(leap + 32768)) << 6) | (unsigned)(63 - t)) : 0u;
+            const unsigned m3 = wave_max_u32(k3);
+            const int bt = 63 - (int)(m3 & 63u); /* wave-uniform winner */
+            const int best = bt - k;
+            const int best_sp = lane_read(sp, bt), best_len = lane_read(len, bt);
+            const int best_cost = lane_read(sw + hc, bt);
+            if (best_len <= 0) break; /* hurdle_matrix.h:358-361 — uniform */
+            // ---- _choose_best_highway ----
+            const V128 best_vec = v_make(
+                (u64)(unsigned)lane_read((int)(unsigned)lo_.lo, bt) | ((u64)(unsigned)lane_read((int)(lo_.lo >> 32), bt) << 32),
+                (u64)(unsigned)lane_read((int)(unsigned)lo_.hi, bt) | ((u64)(unsigned)lane_read((int)(lo_.hi >> 32), bt) << 32));
+            int inter = 0x3fffffff, total = 0x3fffffff;
+            if (active && lane != best && !(sp + fwd_col(lane, best) > best_sp)) {
+                const int endp = sp + len;
+                inter = sw + nh;
+                const int tail = x * v_pop_between(best_vec, fwd_col(lane, best) + endp, best_sp);
+                total = inter + lane_penalty(lane, best, o, e) + (tail > 0 ? tail : 0);
+            }
+            // The reference folds lanes in ascending order, accepting a lane only if it is no worse than the last
+            // accepted one in both total and intermediate cost.  Thresholds only ever go down from best_cost, so lanes
+            // above it can be dropped up front; the few that remain are folded in lane order with scalar code.
+            unsigned long long cmask = __ballot(total <= best_cost && inter <= best_cost);
+            int small_total = best_cost, small_inter = best_cost, ct = bt;
+            while (cmask) {
+                const int j = __builtin_ctzll(cmask);
+                cmask &= cmask - 1ull;
+                const int tj = lane_read(total, j), ij = lane_read(inter, j);
+                if (tj <= small_total && ij <= small_inter) small_total = tj, small_inter = ij, ct = j;
+            }
+            // ---- _step commit (hurdle_matrix.h:411-433) ----
+            cost += lane_read(sw + hc, ct);
+            cur_lane = ct - k;
+            cur_col = lane_read(sp, ct) + lane_read(len, ct);
+            if (cur_col >= lane_destination(m, nn, cur_lane)) break;
+        }
+        if (t == 0) {
+            // ---- final hop (hurdle_matrix.h:575-590) ----
+            const int dest_col = lane_destination(m, nn, dest_lane);
+            if (cur_lane != dest_lane || cur_col < dest_col) {
+                const V128 dv = greedy_lane_vector(A0, A1, B0, B1, dest_lane);
+                const int sw_f = lane_penalty(cur_lane, dest_lane, o, e);
+                const int distance = v_pop_between(dv, cur_col + fwd_col(cur_lane, dest_lane), dest_col);
+                const int hcf = x * distance;
+                cost += sw_f + (hcf > 0 ? hcf : 0);
+            }
+            out[i] = cost;
+        }
+    }
+}
+
+template <typename Kern, typename... Args>
+static inline void launch_wave_per_pair(hipStream_t stream, Kern kern, int64_t n, int num_cus, Args... args) {
+    int per_cu = 8;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, ASM_BLOCK, 0);
+    if (per_cu < 1) per_cu = 1;
+    int64_t blocks = (int64_t)per_cu * num_cus;
+    const int64_t need = (n + 3) / 4; /* four waves (pairs in flight) per workgroup */
+    if (blocks > need) blocks = need;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(ASM_BLOCK), 0, stream, args...);
+}
