@@ -116,3 +116,11 @@ ASM_DEV V128 v_low_ones(int len) {
     u64 hi = h <= 0 ? 0ull : (h >= 64 ? ~0ull : ((1ull << h) - 1ull));
     return v_make(lo, hi);
 }
+
+// Where a kernel's i-th pair writes its penalty: with length-bucketed batches the kernels run over a bucket's pairs
+// in bucket order and `order` maps the bucket slot back to the caller's pair index (null = identity).
+struct OutMap {
+    int32_t* out;
+    const uint32_t* order;
+    ASM_DEV void put(long i, int v) const { out[order ? (long)order[i] : i] = v; }
+};

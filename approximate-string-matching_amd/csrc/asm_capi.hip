@@ -26,6 +26,7 @@ struct asm_handle {
     bool persist = true;                  /* Greedy: lane-refilling persistent kernel (ASM_PERSIST=0 disables) */
     bool persist_leap = false;            /* LEAP: the plain one-pair-per-thread kernel is faster at 1e6 pairs (ASM_PERSIST_LEAP=1) */
     int refill_greedy = 8, refill_leap = 16; /* lanes that must be idle before a wave refills (tunable by env) */
+    bool bucketing = true;                /* group mixed-length batches by width class (ASM_BUCKET=0 disables) */
     bool wave_kernels = true;             /* wave-per-pair kernels for 6 <= k <= 31 (ASM_WAVE=0: workgroup-per-pair LDS kernels) */
     bool nw_banded = true;                /* banded bit-parallel NW with in-kernel full-height recompute (ASM_NW_BANDED=0) */
     unsigned long long* d_work = nullptr; /* work-queue heads for the persistent kernels */
@@ -33,9 +34,18 @@ struct asm_handle {
 };
 #define ASM_WORK_SLOTS 64
 
-struct asm_batch {
+/* One width class of a batch: pairs whose longer string needs `w4` granules of 128 positions. */
+struct asm_bucket {
     int64_t n = 0;
     int w4 = 1;
+    int maxlen = 0;
+    uint4* planes = nullptr;    /* uint4[4][w4][n], inside asm_batch::d_planes */
+    uint32_t* lens = nullptr;   /* uint32[n],       inside asm_batch::d_lens   */
+    uint32_t* order = nullptr;  /* bucket slot -> pair index; null when the batch is one bucket in input order */
+};
+
+struct asm_batch {
+    int64_t n = 0;
     int maxlen = 0;
     int greedy_mode = ASM_GREEDY_CLEAN;
     size_t reads_bytes = 0, refs_bytes = 0;
@@ -43,9 +53,14 @@ struct asm_batch {
     char* d_refs = nullptr;
     uint32_t* d_read_off = nullptr;
     uint32_t* d_ref_off = nullptr;
-    uint4* d_planes = nullptr;
-    uint32_t* d_lens = nullptr;
-    uint4* d_tails = nullptr;
+    uint4* d_planes = nullptr;  /* all buckets back to back */
+    uint32_t* d_lens = nullptr; /* in bucketed order */
+    uint32_t* d_order = nullptr; /* bucketed slot -> pair index (null: identity) */
+    uint32_t* d_pos = nullptr;   /* pair index -> bucketed slot (null: identity) */
+    uint4* d_tails = nullptr;    /* sequential mode: stale-tail planes, uint4[4][n] in input order */
+    int nb = 1;
+    asm_bucket bk[4];
+    PackBuckets pb;
 };
 
 static thread_local std::string g_err;
@@ -82,28 +97,30 @@ static hipError_t launch_persistent(asm_handle* h, Kern kern, int64_t n, Args...
 }
 
 template <int K>
-static hipError_t launch_greedy(asm_handle* h, const asm_batch* b, const GreedyArgs& ga, int32_t* d_out) {
+static hipError_t launch_greedy(asm_handle* h, const asm_bucket& b, const GreedyArgs& ga, OutMap out) {
     if (h->persist)
-        return launch_persistent(h, greedy_persist_kernel<K>, b->n, (const uint4*)b->d_planes, (const uint32_t*)b->d_lens,
-                                 (long)b->n, b->w4, ga, d_out, h->refill_greedy);
-    hipLaunchKernelGGL(greedy_kernel<K>, dim3(grid_for(b->n)), dim3(ASM_BLOCK), 0, h->stream, b->d_planes, b->d_lens,
-                       (long)b->n, b->w4, ga, d_out);
+        return launch_persistent(h, greedy_persist_kernel<K>, b.n, (const uint4*)b.planes, (const uint32_t*)b.lens,
+                                 (long)b.n, b.w4, ga, out, h->refill_greedy);
+    hipLaunchKernelGGL(greedy_kernel<K>, dim3(grid_for(b.n)), dim3(ASM_BLOCK), 0, h->stream, b.planes, b.lens, (long)b.n,
+                       b.w4, ga, out);
     return hipGetLastError();
 }
 
 template <int K, int W64>
-static hipError_t launch_leap_unit_w(asm_handle* h, const asm_batch* b, int32_t* d_out) {
+static hipError_t launch_leap_unit_w(asm_handle* h, const asm_bucket& b, OutMap out) {
     if (h->persist_leap)
-        return launch_persistent(h, leap_unit_persist_kernel<K, W64>, b->n, (const uint4*)b->d_planes,
-                                 (const uint32_t*)b->d_lens, (long)b->n, b->w4, d_out, h->refill_leap);
-    hipLaunchKernelGGL((leap_unit_kernel<K, W64>), dim3(grid_for(b->n)), dim3(ASM_BLOCK), 0, h->stream, b->d_planes,
-                       b->d_lens, (long)b->n, b->w4, d_out);
+        return launch_persistent(h, leap_unit_persist_kernel<K, W64>, b.n, (const uint4*)b.planes, (const uint32_t*)b.lens,
+                                 (long)b.n, b.w4, out, h->refill_leap);
+    hipLaunchKernelGGL((leap_unit_kernel<K, W64>), dim3(grid_for(b.n)), dim3(ASM_BLOCK), 0, h->stream, b.planes, b.lens,
+                       (long)b.n, b.w4, out);
     return hipGetLastError();
 }
 
 template <int K>
-static hipError_t launch_leap_unit(asm_handle* h, const asm_batch* b, int32_t* d_out) {
-    return b->maxlen <= 128 ? launch_leap_unit_w<K, 2>(h, b, d_out) : launch_leap_unit_w<K, 4>(h, b, d_out);
+static hipError_t launch_leap_unit(asm_handle* h, const asm_bucket& b, OutMap out) {
+    if (b.maxlen <= 128) return launch_leap_unit_w<K, 2>(h, b, out);
+    if (b.maxlen <= 256) return launch_leap_unit_w<K, 4>(h, b, out);
+    return launch_leap_unit_w<K, 6>(h, b, out);
 }
 
 extern "C" {
@@ -144,6 +161,7 @@ int asm_create(asm_handle** out, int device) {
     const char* env = getenv("ASM_PERSIST");
     h->persist = !(env && env[0] == '0');
     if ((env = getenv("ASM_PERSIST_LEAP"))) h->persist_leap = env[0] != '0';
+    if ((env = getenv("ASM_BUCKET"))) h->bucketing = env[0] != '0';
     if ((env = getenv("ASM_WAVE"))) h->wave_kernels = env[0] != '0';
     if ((env = getenv("ASM_NW_BANDED"))) h->nw_banded = env[0] != '0';
     if ((env = getenv("ASM_REFILL_GREEDY"))) h->refill_greedy = atoi(env);
@@ -237,58 +255,166 @@ static void batch_release(asm_batch* b) {
     (void)hipFree(b->d_ref_off);
     (void)hipFree(b->d_planes);
     (void)hipFree(b->d_lens);
+    (void)hipFree(b->d_order);
+    (void)hipFree(b->d_pos);
     (void)hipFree(b->d_tails);
     delete b;
 }
 
-static int batch_alloc_packed(asm_handle* h, asm_batch* b) {
-    HIPCHK(h, hipMalloc((void**)&b->d_planes, sizeof(uint4) * 4 * (size_t)b->w4 * (size_t)(b->n > 0 ? b->n : 1)));
-    HIPCHK(h, hipMalloc((void**)&b->d_lens, sizeof(uint32_t) * (size_t)(b->n > 0 ? b->n : 1)));
-    return ASM_OK;
-}
-
-int asm_batch_pack_async(asm_handle* h, asm_batch* b) {
-    if (!h || !b) return fail(h, ASM_EINVAL, "asm_batch_pack_async: NULL argument");
-    if (b->n == 0) return ASM_OK;
-    HIPCHK(h, hipSetDevice(h->device));
+static hipError_t launch_pack(asm_handle* h, const asm_batch* b, const uint4* tails, uint4* planes, uint32_t* lens,
+                              const PackBuckets& pb, const uint32_t* pos) {
     const dim3 grid((unsigned)((b->n + ASM_BLOCK - 1) / ASM_BLOCK)), block(ASM_BLOCK);
+    int wmax = 1;
+    for (int q = 0; q < pb.nb; q++) wmax = pb.w4[q] > wmax ? pb.w4[q] : wmax;
 #define PACK_LAUNCH(W)                                                                                            \
     hipLaunchKernelGGL(pack_kernel<W>, grid, block, 0, h->stream, b->d_reads, b->d_read_off, b->d_refs, b->d_ref_off, \
-                       b->d_tails, b->d_planes, b->d_lens, (long)b->n, b->w4)
-    switch (b->w4) {
+                       tails, planes, lens, (long)b->n, pb, pos)
+    switch (wmax) {
         case 1: PACK_LAUNCH(1); break;
         case 2: PACK_LAUNCH(2); break;
         case 3: PACK_LAUNCH(3); break;
         default: PACK_LAUNCH(4); break;
     }
 #undef PACK_LAUNCH
-    HIPCHK(h, hipGetLastError());
+    return hipGetLastError();
+}
+
+int asm_batch_pack_async(asm_handle* h, asm_batch* b) {
+    if (!h || !b) return fail(h, ASM_EINVAL, "asm_batch_pack_async: NULL argument");
+    if (b->n == 0) return ASM_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, launch_pack(h, b, b->d_tails, b->d_planes, b->d_lens, b->pb, b->d_pos));
     return ASM_OK;
 }
 
-/* ASM_GREEDY_SEQUENTIAL: derive the stale buffer tails on the device (asm_tails.h) from the clean-mode planes that
- * the first pack produced, then pack again so that granule 0 carries them. */
+/* ASM_GREEDY_SEQUENTIAL: derive the stale buffer tails on the device (asm_tails.h).  The resolver walks the pairs
+ * in INPUT order and only needs granule 0, so it works on a temporary clean-mode, unbucketed, one-granule packing. */
 static int batch_resolve_tails(asm_handle* h, asm_batch* b) {
     if (b->n == 0) return ASM_OK;
     const long nchunks = (b->n + TAIL_CHUNK - 1) / TAIL_CHUNK;
     uint8_t *d_last = nullptr, *d_carry = nullptr;
-    HIPCHK(h, hipMalloc((void**)&b->d_tails, sizeof(uint4) * 4 * (size_t)b->n));
-    HIPCHK(h, hipMalloc((void**)&d_last, (size_t)nchunks * 256));
-    HIPCHK(h, hipMalloc((void**)&d_carry, (size_t)nchunks * 256));
-    uint4* tails = b->d_tails;
-    b->d_tails = nullptr; /* the planes read below must be the clean ones; pack has already run without tails */
-    hipLaunchKernelGGL(tails_chunk_kernel, dim3((unsigned)nchunks), dim3(256), 0, h->stream, b->d_planes, b->d_lens,
-                       (long)b->n, b->w4, d_last);
-    hipLaunchKernelGGL(tails_carry_kernel, dim3(1), dim3(256), 0, h->stream, d_last, d_carry, nchunks);
-    hipLaunchKernelGGL(tails_emit_kernel, dim3((unsigned)nchunks), dim3(256), 0, h->stream, b->d_planes, b->d_lens,
-                       (long)b->n, b->w4, d_carry, tails);
-    hipError_t e = hipGetLastError();
-    b->d_tails = tails;
-    int rc = e == hipSuccess ? asm_batch_pack_async(h, b) : fail(h, ASM_ENODEVICE, hipGetErrorString(e));
-    hipError_t e2 = hipStreamSynchronize(h->stream);
+    uint4* d_g0 = nullptr;
+    uint32_t* d_l0 = nullptr;
+    int rc = ASM_OK;
+    do {
+#define TRY(call)                                                        \
+    if ((call) != hipSuccess) {                                          \
+        rc = fail(h, ASM_ENODEVICE, std::string(#call) + " failed");     \
+        break;                                                           \
+    }
+        TRY(hipMalloc((void**)&b->d_tails, sizeof(uint4) * 4 * (size_t)b->n));
+        TRY(hipMalloc((void**)&d_g0, sizeof(uint4) * 4 * (size_t)b->n));
+        TRY(hipMalloc((void**)&d_l0, sizeof(uint32_t) * (size_t)b->n));
+        TRY(hipMalloc((void**)&d_last, (size_t)nchunks * 256));
+        TRY(hipMalloc((void**)&d_carry, (size_t)nchunks * 256));
+        PackBuckets one{};
+        one.nb = 1, one.w4[0] = 1, one.start[0] = 0, one.start[1] = b->n, one.plane_off[0] = 0;
+        TRY(launch_pack(h, b, nullptr, d_g0, d_l0, one, nullptr));
+        hipLaunchKernelGGL(tails_chunk_kernel, dim3((unsigned)nchunks), dim3(256), 0, h->stream, d_g0, d_l0, (long)b->n, 1,
+                           d_last);
+        hipLaunchKernelGGL(tails_carry_kernel, dim3(1), dim3(256), 0, h->stream, d_last, d_carry, nchunks);
+        hipLaunchKernelGGL(tails_emit_kernel, dim3((unsigned)nchunks), dim3(256), 0, h->stream, d_g0, d_l0, (long)b->n, 1,
+                           d_carry, b->d_tails);
+        TRY(hipGetLastError());
+        TRY(hipStreamSynchronize(h->stream));
+#undef TRY
+    } while (0);
     (void)hipFree(d_last);
     (void)hipFree(d_carry);
-    if (!rc && e2 != hipSuccess) rc = fail(h, ASM_ENODEVICE, hipGetErrorString(e2));
+    (void)hipFree(d_g0);
+    (void)hipFree(d_l0);
+    return rc;
+}
+
+/* Common tail of upload/generate once ASCII + offsets are resident and b->maxlen is known: group the pairs into width
+ * classes (only when the batch really mixes classes), allocate the packed form, resolve tails, pack. */
+static int batch_finish(asm_handle* h, asm_batch* b) {
+    const int64_t n = b->n;
+    const int wmax = b->maxlen <= 128 ? 1 : (b->maxlen + 127) / 128;
+    unsigned int counts[4] = {0, 0, 0, 0};
+    uint8_t *d_cls = nullptr, *d_cls2 = nullptr;
+    uint32_t* d_idx = nullptr;
+    unsigned int* d_counts = nullptr;
+    void* d_tmp = nullptr;
+    int rc = ASM_OK;
+    do {
+#define TRY(call)                                                        \
+    if ((call) != hipSuccess) {                                          \
+        rc = fail(h, ASM_ENODEVICE, std::string(#call) + " failed");     \
+        break;                                                           \
+    }
+        bool bucketed = false;
+        if (wmax > 1 && n >= 4096 && h->bucketing) {
+            TRY(hipMalloc((void**)&d_cls, (size_t)n));
+            TRY(hipMalloc((void**)&d_cls2, (size_t)n));
+            TRY(hipMalloc((void**)&d_idx, sizeof(uint32_t) * (size_t)n));
+            TRY(hipMalloc((void**)&d_counts, 16));
+            TRY(hipMemsetAsync(d_counts, 0, 16, h->stream));
+            hipLaunchKernelGGL(classify_kernel, dim3(grid_for(n)), dim3(ASM_BLOCK), 0, h->stream, b->d_read_off, b->d_ref_off,
+                               (long)n, d_cls, d_idx, d_counts);
+            TRY(hipGetLastError());
+            TRY(hipMemcpyAsync(counts, d_counts, 16, hipMemcpyDeviceToHost, h->stream));
+            TRY(hipStreamSynchronize(h->stream));
+            int classes = 0;
+            for (int c = 0; c < 4; c++) classes += counts[c] ? 1 : 0;
+            bucketed = classes > 1;
+            if (bucketed) {
+                TRY(hipMalloc((void**)&b->d_order, sizeof(uint32_t) * (size_t)n));
+                TRY(hipMalloc((void**)&b->d_pos, sizeof(uint32_t) * (size_t)n));
+                size_t tmp_bytes = 0;
+                TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_cls, d_cls2, d_idx, b->d_order, (int)n, 0, 2,
+                                                       h->stream));
+                TRY(hipMalloc(&d_tmp, tmp_bytes + 16));
+                TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_cls, d_cls2, d_idx, b->d_order, (int)n, 0, 2,
+                                                       h->stream)); /* stable: input order is kept inside a class */
+                hipLaunchKernelGGL(invert_order_kernel, dim3(grid_for(n)), dim3(ASM_BLOCK), 0, h->stream, b->d_order, (long)n,
+                                   b->d_pos);
+                TRY(hipGetLastError());
+            }
+        }
+        // bucket table
+        b->nb = 0;
+        size_t plane_total = 0;
+        int64_t slot = 0;
+        b->pb = PackBuckets{};
+        if (!bucketed) {
+            counts[0] = counts[1] = counts[2] = counts[3] = 0;
+            counts[wmax - 1] = (unsigned int)n;
+        }
+        for (int c = 0; c < 4; c++) {
+            if (!counts[c] && !(n == 0 && c == 0)) continue;
+            asm_bucket& k = b->bk[b->nb];
+            k.n = counts[c];
+            k.w4 = c + 1;
+            k.maxlen = b->maxlen < 128 * (c + 1) ? b->maxlen : 128 * (c + 1);
+            b->pb.w4[b->nb] = k.w4;
+            b->pb.start[b->nb] = slot;
+            b->pb.plane_off[b->nb] = (long)plane_total;
+            plane_total += (size_t)4 * (size_t)k.w4 * (size_t)k.n;
+            slot += k.n;
+            b->nb++;
+        }
+        b->pb.nb = b->nb;
+        b->pb.start[b->nb] = slot;
+        TRY(hipMalloc((void**)&b->d_planes, sizeof(uint4) * (plane_total ? plane_total : 1)));
+        TRY(hipMalloc((void**)&b->d_lens, sizeof(uint32_t) * (size_t)(n > 0 ? n : 1)));
+        for (int q = 0; q < b->nb; q++) {
+            b->bk[q].planes = b->d_planes + b->pb.plane_off[q];
+            b->bk[q].lens = b->d_lens + b->pb.start[q];
+            b->bk[q].order = b->d_order ? b->d_order + b->pb.start[q] : nullptr;
+        }
+#undef TRY
+        if (b->greedy_mode == ASM_GREEDY_SEQUENTIAL) rc = batch_resolve_tails(h, b);
+        if (rc) break;
+        rc = asm_batch_pack_async(h, b);
+        if (rc) break;
+        if (hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(h, ASM_ENODEVICE, "batch: stream synchronize failed");
+    } while (0);
+    (void)hipFree(d_cls);
+    (void)hipFree(d_cls2);
+    (void)hipFree(d_idx);
+    (void)hipFree(d_counts);
+    (void)hipFree(d_tmp);
     return rc;
 }
 
@@ -313,7 +439,6 @@ int asm_batch_upload(asm_handle* h, int64_t n, const char* reads, const uint32_t
     asm_batch* b = new asm_batch;
     b->n = n;
     b->maxlen = maxlen;
-    b->w4 = maxlen <= 128 ? 1 : (maxlen + 127) / 128;
     b->greedy_mode = greedy_mode;
     b->reads_bytes = n ? read_off[n] : 0;
     b->refs_bytes = n ? ref_off[n] : 0;
@@ -333,16 +458,7 @@ int asm_batch_upload(asm_handle* h, int64_t n, const char* reads, const uint32_t
         TRY(hipMemcpyAsync(b->d_read_off, read_off, sizeof(uint32_t) * (size_t)(n + 1), hipMemcpyHostToDevice, h->stream));
         TRY(hipMemcpyAsync(b->d_ref_off, ref_off, sizeof(uint32_t) * (size_t)(n + 1), hipMemcpyHostToDevice, h->stream));
 #undef TRY
-        rc = batch_alloc_packed(h, b);
-        if (rc) break;
-        rc = asm_batch_pack_async(h, b);
-        if (rc) break;
-        if (greedy_mode == ASM_GREEDY_SEQUENTIAL) rc = batch_resolve_tails(h, b);
-        if (rc) break;
-        if (hipStreamSynchronize(h->stream) != hipSuccess) {
-            rc = fail(h, ASM_ENODEVICE, "asm_batch_upload: stream synchronize failed");
-            break;
-        }
+        rc = batch_finish(h, b);
     } while (0);
     if (rc) {
         batch_release(b);
@@ -415,7 +531,6 @@ int asm_batch_generate(asm_handle* h, const asm_gen_config* cfg, int64_t first, 
             rc = fail(h, ASM_EUNSUPPORTED, "asm_batch_generate: a generated sequence exceeds ASM_MAX_LENGTH");
             break;
         }
-        b->w4 = b->maxlen <= 128 ? 1 : (b->maxlen + 127) / 128;
         TRY(hipMalloc((void**)&b->d_reads, b->reads_bytes + 16));
         TRY(hipMalloc((void**)&b->d_refs, b->refs_bytes + 16));
         if (n > 0) {
@@ -424,16 +539,7 @@ int asm_batch_generate(asm_handle* h, const asm_gen_config* cfg, int64_t first, 
             TRY(hipGetLastError());
         }
 #undef TRY
-        rc = batch_alloc_packed(h, b);
-        if (rc) break;
-        rc = asm_batch_pack_async(h, b);
-        if (rc) break;
-        if (greedy_mode == ASM_GREEDY_SEQUENTIAL) rc = batch_resolve_tails(h, b);
-        if (rc) break;
-        if (hipStreamSynchronize(h->stream) != hipSuccess) {
-            rc = fail(h, ASM_ENODEVICE, "asm_batch_generate: stream synchronize failed");
-            break;
-        }
+        rc = batch_finish(h, b);
     } while (0);
     (void)hipFree(d_m);
     (void)hipFree(d_n);
@@ -495,13 +601,12 @@ static int check_params(asm_handle* h, int aligner, const asm_params* p) {
     return ASM_OK;
 }
 
-int asm_align_batch_async(asm_handle* h, const asm_batch* b, int aligner, const asm_params* p, int32_t* d_penalties) {
-    if (!h || !b || !d_penalties) return fail(h, ASM_EINVAL, "asm_align_batch_async: NULL argument");
-    int rc = check_params(h, aligner, p);
-    if (rc) return rc;
-    if (b->n == 0) return ASM_OK;
-    HIPCHK(h, hipSetDevice(h->device));
+/* one aligner over one width class */
+static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const asm_params* p, OutMap out) {
+    if (b.n == 0) return ASM_OK;
     const bool unit = (p->x == 1 && p->o == 1 && p->e == 1);
+    const uint4* planes = b.planes;
+    const uint32_t* lens = b.lens;
     if (aligner == ASM_GREEDY) {
         GreedyArgs ga;
         ga.x = p->x, ga.o = p->o, ga.e = p->e;
@@ -509,33 +614,32 @@ int asm_align_batch_async(asm_handle* h, const asm_batch* b, int aligner, const 
         ga.sig_mismatch = log(p->p_mismatch / 0.25);
         ga.sig_indel = log(p->p_indel / 2 / 0.25);
         switch (p->k) {
-            case 1: HIPCHK(h, launch_greedy<1>(h, b, ga, d_penalties)); break;
-            case 2: HIPCHK(h, launch_greedy<2>(h, b, ga, d_penalties)); break;
-            case 3: HIPCHK(h, launch_greedy<3>(h, b, ga, d_penalties)); break;
-            case 4: HIPCHK(h, launch_greedy<4>(h, b, ga, d_penalties)); break;
-            case 5: HIPCHK(h, launch_greedy<5>(h, b, ga, d_penalties)); break;
+            case 1: HIPCHK(h, launch_greedy<1>(h, b, ga, out)); break;
+            case 2: HIPCHK(h, launch_greedy<2>(h, b, ga, out)); break;
+            case 3: HIPCHK(h, launch_greedy<3>(h, b, ga, out)); break;
+            case 4: HIPCHK(h, launch_greedy<4>(h, b, ga, out)); break;
+            case 5: HIPCHK(h, launch_greedy<5>(h, b, ga, out)); break;
             default:
                 if (p->k <= ASM_WAVE_MAX_K && h->wave_kernels && (long)p->o + 62L * p->e < 16000L)
-                    launch_wave_per_pair(h->stream, greedy_wave_kernel, b->n, h->num_cus, (const uint4*)b->d_planes,
-                                         (const uint32_t*)b->d_lens, (long)b->n, b->w4, (int)p->k, ga, d_penalties);
+                    launch_wave_per_pair(h->stream, greedy_wave_kernel, b.n, h->num_cus, planes, lens, (long)b.n, b.w4,
+                                         (int)p->k, ga, out);
                 else
-                    launch_greedy_wide(h->stream, b->d_planes, b->d_lens, b->n, b->w4, p->k, ga, d_penalties);
+                    launch_greedy_wide(h->stream, planes, lens, b.n, b.w4, p->k, ga, out);
                 break;
         }
     } else if (aligner == ASM_LEAP) {
-        if (unit && p->k >= 1 && p->k <= 5 && b->maxlen <= 256) {
+        if (unit && p->k >= 1 && p->k <= 5 && b.maxlen <= 384) {
             switch (p->k) {
-                case 1: HIPCHK(h, launch_leap_unit<1>(h, b, d_penalties)); break;
-                case 2: HIPCHK(h, launch_leap_unit<2>(h, b, d_penalties)); break;
-                case 3: HIPCHK(h, launch_leap_unit<3>(h, b, d_penalties)); break;
-                case 4: HIPCHK(h, launch_leap_unit<4>(h, b, d_penalties)); break;
-                default: HIPCHK(h, launch_leap_unit<5>(h, b, d_penalties)); break;
+                case 1: HIPCHK(h, launch_leap_unit<1>(h, b, out)); break;
+                case 2: HIPCHK(h, launch_leap_unit<2>(h, b, out)); break;
+                case 3: HIPCHK(h, launch_leap_unit<3>(h, b, out)); break;
+                case 4: HIPCHK(h, launch_leap_unit<4>(h, b, out)); break;
+                default: HIPCHK(h, launch_leap_unit<5>(h, b, out)); break;
             }
         } else if (unit && p->k <= ASM_WAVE_MAX_K && h->wave_kernels) {
-#define LEAP_WAVE(W)                                                                                               \
-    launch_wave_per_pair(h->stream, leap_wave_kernel<W>, b->n, h->num_cus, (const uint4*)b->d_planes,              \
-                         (const uint32_t*)b->d_lens, (long)b->n, b->w4, (int)p->k, d_penalties)
-            switch (b->w4) {
+#define LEAP_WAVE(W) \
+    launch_wave_per_pair(h->stream, leap_wave_kernel<W>, b.n, h->num_cus, planes, lens, (long)b.n, b.w4, (int)p->k, out)
+            switch (b.w4) {
                 case 1: LEAP_WAVE(2); break;
                 case 2: LEAP_WAVE(4); break;
                 case 3: LEAP_WAVE(6); break;
@@ -543,34 +647,50 @@ int asm_align_batch_async(asm_handle* h, const asm_batch* b, int aligner, const 
             }
 #undef LEAP_WAVE
         } else {
-            launch_leap_wide(h->stream, b->d_planes, b->d_lens, b->n, b->w4, p->k, p->x, p->o, p->e, d_penalties);
+            launch_leap_wide(h->stream, planes, lens, b.n, b.w4, p->k, p->x, p->o, p->e, out);
         }
     } else {
         if (unit) {
-            const dim3 g(grid_for(b->n)), t(ASM_BLOCK);
+            const dim3 g(grid_for(b.n)), t(ASM_BLOCK);
+            const long n = (long)b.n;
             if (!h->nw_banded) {
-                if (b->maxlen <= 128)
-                    hipLaunchKernelGGL(nw_unit_kernel<2>, g, t, 0, h->stream, b->d_planes, b->d_lens, (long)b->n, b->w4, d_penalties);
-                else if (b->maxlen <= 256)
-                    hipLaunchKernelGGL(nw_unit_kernel<4>, g, t, 0, h->stream, b->d_planes, b->d_lens, (long)b->n, b->w4, d_penalties);
-                else if (b->maxlen <= 384)
-                    hipLaunchKernelGGL(nw_unit_kernel<6>, g, t, 0, h->stream, b->d_planes, b->d_lens, (long)b->n, b->w4, d_penalties);
+                if (b.w4 == 1)
+                    hipLaunchKernelGGL(nw_unit_kernel<2>, g, t, 0, h->stream, planes, lens, n, b.w4, out);
+                else if (b.w4 == 2)
+                    hipLaunchKernelGGL(nw_unit_kernel<4>, g, t, 0, h->stream, planes, lens, n, b.w4, out);
+                else if (b.w4 == 3)
+                    hipLaunchKernelGGL(nw_unit_kernel<6>, g, t, 0, h->stream, planes, lens, n, b.w4, out);
                 else
-                    hipLaunchKernelGGL(nw_unit_kernel<8>, g, t, 0, h->stream, b->d_planes, b->d_lens, (long)b->n, b->w4, d_penalties);
-            } else if (b->w4 == 1)
-                hipLaunchKernelGGL(nw_banded_kernel<4>, g, t, 0, h->stream, b->d_planes, b->d_lens, (long)b->n, b->w4, d_penalties);
-            else if (b->w4 == 2)
-                hipLaunchKernelGGL(nw_banded_kernel<8>, g, t, 0, h->stream, b->d_planes, b->d_lens, (long)b->n, b->w4, d_penalties);
-            else if (b->w4 == 3)
-                hipLaunchKernelGGL(nw_banded_kernel<12>, g, t, 0, h->stream, b->d_planes, b->d_lens, (long)b->n, b->w4, d_penalties);
+                    hipLaunchKernelGGL(nw_unit_kernel<8>, g, t, 0, h->stream, planes, lens, n, b.w4, out);
+            } else if (b.w4 == 1)
+                hipLaunchKernelGGL((nw_banded_kernel<4, 32>), g, t, 0, h->stream, planes, lens, n, b.w4, out);
+            else if (b.w4 == 2)
+                hipLaunchKernelGGL((nw_banded_kernel<8, 64>), g, t, 0, h->stream, planes, lens, n, b.w4, out);
+            else if (b.w4 == 3)
+                hipLaunchKernelGGL((nw_banded_kernel<12, 64>), g, t, 0, h->stream, planes, lens, n, b.w4, out);
             else
-                hipLaunchKernelGGL(nw_banded_kernel<16>, g, t, 0, h->stream, b->d_planes, b->d_lens, (long)b->n, b->w4, d_penalties);
+                hipLaunchKernelGGL((nw_banded_kernel<16, 64>), g, t, 0, h->stream, planes, lens, n, b.w4, out);
         } else {
-            launch_nw_affine(h->stream, b->d_planes, b->d_lens, b->n, b->w4, b->maxlen, p->x, p->o, p->e, d_penalties);
+            launch_nw_affine(h->stream, planes, lens, b.n, b.w4, b.maxlen, p->x, p->o, p->e, out);
         }
     }
     HIPCHK(h, hipGetLastError());
     return ASM_OK;
+}
+
+int asm_align_batch_async(asm_handle* h, const asm_batch* b, int aligner, const asm_params* p, int32_t* d_penalties) {
+    if (!h || !b || !d_penalties) return fail(h, ASM_EINVAL, "asm_align_batch_async: NULL argument");
+    int rc = check_params(h, aligner, p);
+    if (rc) return rc;
+    if (b->n == 0) return ASM_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    for (int q = 0; q < b->nb && !rc; q++) {
+        OutMap out;
+        out.out = d_penalties;
+        out.order = b->bk[q].order;
+        rc = align_bucket(h, b->bk[q], aligner, p, out);
+    }
+    return rc;
 }
 
 int asm_align_batch(asm_handle* h, int aligner, int64_t n, const char* reads, const uint32_t* read_off, const char* refs,

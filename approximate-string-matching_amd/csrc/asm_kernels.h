@@ -36,6 +36,16 @@
 // --------------------------------------------------------------------------------------------------------
 #define PACK_SB (48 * 1024)
 
+// Length buckets of a batch (mixed-length batches are grouped by the number of 128-position granules their longer
+// string needs, so that every kernel launch works on pairs of one width class).  Bucket b holds the pairs at slots
+// [start[b], start[b+1]) of the bucketed order; its planes are a uint4[4][w4[b]][size] block at plane_off[b].
+struct PackBuckets {
+    int nb;
+    int w4[4];
+    long start[5];
+    long plane_off[4];
+};
+
 ASM_DEV uint32_t swar_zero_bytes(uint32_t t) { /* bit 7 of each byte set iff that byte of t is zero (exact) */
     return ~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t | 0x7f7f7f7fu);
 }
@@ -47,7 +57,8 @@ __global__ __launch_bounds__(ASM_BLOCK) void pack_kernel(const char* __restrict_
                                                          const uint32_t* __restrict__ ref_off,
                                                          const uint4* __restrict__ tails, /* [4][n] or null */
                                                          uint4* __restrict__ planes, uint32_t* __restrict__ lens,
-                                                         long n, int w4) {
+                                                         long n, PackBuckets pb,
+                                                         const uint32_t* __restrict__ pos /* pair -> slot, or null */) {
     __shared__ uint4 s_buf[PACK_SB / 16 + 4];
     __shared__ uint32_t s_off[ASM_BLOCK + 1];
     const int t = threadIdx.x;
@@ -55,6 +66,15 @@ __global__ __launch_bounds__(ASM_BLOCK) void pack_kernel(const char* __restrict_
     const int np = (n - p0) < ASM_BLOCK ? (int)(n - p0) : ASM_BLOCK;
     const uint32_t* sb = reinterpret_cast<const uint32_t*>(s_buf);
     uint32_t my_len[2] = {0u, 0u};
+    // where this thread's pair lives in the bucketed layout
+    const long slot = (t < np) ? (pos ? (long)pos[p0 + t] : p0 + t) : 0;
+    int bk = 0;
+#pragma unroll
+    for (int q = 1; q < 4; q++)
+        if (q < pb.nb && slot >= pb.start[q]) bk = q;
+    const int w4 = pb.w4[bk];
+    const long bn = pb.start[bk + 1] - pb.start[bk], local = slot - pb.start[bk];
+    uint4* bplanes = planes + pb.plane_off[bk];
 #pragma unroll 1
     for (int s = 0; s < 2; s++) {
         const char* str = s ? refs : reads;
@@ -120,8 +140,8 @@ __global__ __launch_bounds__(ASM_BLOCK) void pack_kernel(const char* __restrict_
                             v0.x |= t0.x, v0.y |= t0.y, v0.z |= t0.z, v0.w |= t0.w;
                             v1.x |= t1.x, v1.y |= t1.y, v1.z |= t1.z, v1.w |= t1.w;
                         }
-                        planes[((long)(2 * s) * w4 + g) * n + p0 + t] = v0;
-                        planes[((long)(2 * s + 1) * w4 + g) * n + p0 + t] = v1;
+                        bplanes[((long)(2 * s) * w4 + g) * bn + local] = v0;
+                        bplanes[((long)(2 * s + 1) * w4 + g) * bn + local] = v1;
                     }
                 }
             }
@@ -129,7 +149,36 @@ __global__ __launch_bounds__(ASM_BLOCK) void pack_kernel(const char* __restrict_
             ps = pe;
         }
     }
-    if (t < np) lens[p0 + t] = my_len[0] | (my_len[1] << 16);
+    if (t < np) lens[slot] = my_len[0] | (my_len[1] << 16);
+}
+
+// width class of every pair (granules of the longer string, minus one) and the class histogram
+__global__ __launch_bounds__(ASM_BLOCK) void classify_kernel(const uint32_t* __restrict__ read_off,
+                                                             const uint32_t* __restrict__ ref_off, long n,
+                                                             uint8_t* __restrict__ cls, uint32_t* __restrict__ idx,
+                                                             unsigned int* __restrict__ counts /* [4] */) {
+    __shared__ unsigned int s_cnt[4];
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const uint32_t m = read_off[i + 1] - read_off[i], nn = ref_off[i + 1] - ref_off[i];
+        uint32_t L = m > nn ? m : nn;
+        L = L < 1u ? 1u : L;
+        uint32_t c = (L + 127u) / 128u - 1u;
+        c = c > 3u ? 3u : c;
+        cls[i] = (uint8_t)c;
+        idx[i] = (uint32_t)i;
+        atomicAdd(&s_cnt[c], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 && s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(ASM_BLOCK) void invert_order_kernel(const uint32_t* __restrict__ order, long n,
+                                                                 uint32_t* __restrict__ pos) {
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) pos[order[j]] = (uint32_t)j;
 }
 
 // --------------------------------------------------------------------------------------------------------
@@ -167,7 +216,7 @@ ASM_DEV V128 greedy_lane_vector(V128 A0, V128 A1, V128 B0, V128 B1, int lane) {
 template <int K>
 __global__ __launch_bounds__(ASM_BLOCK) void greedy_kernel(const uint4* __restrict__ planes,
                                                            const uint32_t* __restrict__ lens, long n, int w4,
-                                                           GreedyArgs args, int32_t* __restrict__ out) {
+                                                           GreedyArgs args, OutMap out) {
     constexpr int NL = 2 * K + 1;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -299,7 +348,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_kernel(const uint4* __restri
         const int hc = x * distance;
         cost += sw_f + (hc > 0 ? hc : 0);
     }
-    out[i] = cost;
+    out.put(i, cost);
 }
 
 // Wave-local work queue for the persistent kernels: every wave owns a contiguous slice [q_next, q_end) of the batch
@@ -336,7 +385,7 @@ struct WaveQueue {
 template <int K>
 __global__ __launch_bounds__(ASM_BLOCK) void greedy_persist_kernel(const uint4* __restrict__ planes,
                                                                    const uint32_t* __restrict__ lens, long n, int w4,
-                                                                   GreedyArgs args, int32_t* __restrict__ out,
+                                                                   GreedyArgs args, OutMap out,
                                                                    int refill_min) {
     constexpr int NL = 2 * K + 1;
     const int x = args.x, o = args.o, e = args.e;
@@ -368,7 +417,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_persist_kernel(const uint4* 
                     const int hc = x * distance;
                     cost += sw_f + (hc > 0 ? hc : 0);
                 }
-                out[idx] = cost;
+                out.put(idx, cost);
             }
             const long got = wq.pull(need);
             if (need) {
@@ -572,7 +621,7 @@ ASM_DEV VW<W64> leap_lane_mask(const VW<W64>& A0, const VW<W64>& A1, const VW<W6
 template <int K, int W64>
 __global__ __launch_bounds__(ASM_BLOCK) void leap_unit_kernel(const uint4* __restrict__ planes,
                                                               const uint32_t* __restrict__ lens, long n, int w4,
-                                                              int32_t* __restrict__ out) {
+                                                              OutMap out) {
     constexpr int NL = 2 * K + 1;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -639,7 +688,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void leap_unit_kernel(const uint4* __res
         for (int j = 0; j < NL; j++) en[j] = en2[j], ip[j] = ip2[j], dp[j] = dp2[j];
         if (pass) result = e; /* final_ED (LV_BAG.cpp:228,356-358), not converge_ED */
     }
-    out[i] = result;
+    out.put(i, result);
 }
 
 // Persistent, lane-refilling form of leap_unit_kernel<K,W64>: a pair needs final_ED+1 generations (mean ~8, max >30
@@ -647,7 +696,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void leap_unit_kernel(const uint4* __res
 template <int K, int W64>
 __global__ __launch_bounds__(ASM_BLOCK) void leap_unit_persist_kernel(const uint4* __restrict__ planes,
                                                                       const uint32_t* __restrict__ lens, long n,
-                                                                      int w4, int32_t* __restrict__ out,
+                                                                      int w4, OutMap out,
                                                                       int refill_min) {
     constexpr int NL = 2 * K + 1;
     VW<W64> mask[NL];
@@ -669,7 +718,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void leap_unit_persist_kernel(const uint
         // (or nothing else is left to do) before paying for it.
         const unsigned long long need_mask = __ballot(need);
         if (need_mask != 0ull && (__popcll(need_mask) >= refill_min || __ballot(active && !finished) == 0ull)) {
-            if (need && active) out[idx] = result;
+            if (need && active) out.put(idx, result);
             const long got = wq.pull(need);
             if (need) {
                 idx = got;
@@ -807,14 +856,14 @@ ASM_DEV int nw_unit_full(const VW<W64>& A0, const VW<W64>& A1, const VW<W64>& B0
 template <int W64>
 __global__ __launch_bounds__(ASM_BLOCK) void nw_unit_kernel(const uint4* __restrict__ planes,
                                                             const uint32_t* __restrict__ lens, long n, int w4,
-                                                            int32_t* __restrict__ out) {
+                                                            OutMap out) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t ln = lens[i];
     const int m = (int)(ln & 0xffffu), nn = (int)(ln >> 16);
     VW<W64> A0, A1, B0, B1;
     load_planes<W64>(planes, n, w4, i, A0, A1, B0, B1);
-    out[i] = nw_unit_full<W64>(A0, A1, B0, B1, m, nn);
+    out.put(i, nw_unit_full<W64>(A0, A1, B0, B1, m, nn));
 }
 
 // --------------------------------------------------------------------------------------------------------
@@ -828,18 +877,93 @@ __global__ __launch_bounds__(ASM_BLOCK) void nw_unit_kernel(const uint4* __restr
 // by the full-height sweep in the same kernel.  At the benchmark's error rates no pair needs the recompute.
 // Rows beyond the read's end hold arbitrary plane bits: they only feed cells below row m, never D[m][n].
 // --------------------------------------------------------------------------------------------------------
-#define NW_BAND_C 16    /* window top row of column j is max(1, j - 15) */
-#define NW_BAND_KMAX 15 /* results up to this are proven exact */
+// The window is W = 32 or 64 rows tall (one dword / one 64-bit pair per vector): rows j-W/2+1 .. j+W/2 of column j,
+// proven exact for results up to W/2 - 1.  A kernel tries the narrow window first where the batch is short, then the
+// 64-row window, then the full-height sweep.
+template <int W>
+struct BandWord;
+template <>
+struct BandWord<32> {
+    typedef uint32_t T;
+};
+template <>
+struct BandWord<64> {
+    typedef u64 T;
+};
 
-template <int ND> /* plane dwords per string: 4 * w4 */
+template <int ND, int W> /* ND = plane dwords per string (4 * w4); A arrays carry two zero dwords of padding */
+ASM_DEV int nw_band(const uint32_t (&A0)[ND + 2], const uint32_t (&A1)[ND + 2], const uint32_t (&B0)[ND],
+                    const uint32_t (&B1)[ND], int m, int nn) {
+    typedef typename BandWord<W>::T WT;
+    constexpr int C = W / 2;          /* window top row of column j is max(1, j - C + 1) */
+    constexpr int NBLK = ND * 32 / W; /* W-column blocks */
+    constexpr WT TOP = (WT)1 << (W - 1);
+#define BLK(ARR, q) (W == 32 ? (WT)ARR[(q)] : (WT)((u64)ARR[2 * (q)] | ((u64)ARR[2 * (q) + 1] << 32)))
+    WT VP = ~(WT)0, VN = 0; /* column 0: D[i][0] = i */
+    int S = W;              /* D[bottom row of the window][column] */
+    WT lo0 = BLK(A0, 0), lo1 = BLK(A1, 0), hi0 = 0, hi1 = 0;
+
+#define NW_BAND_COLUMN(SLIDE, BW0, BW1, R)                                                           \
+    {                                                                                                 \
+        if (SLIDE) {                                                                                  \
+            lo0 = (lo0 >> 1) | (hi0 << (W - 1)), hi0 >>= 1;                                           \
+            lo1 = (lo1 >> 1) | (hi1 << (W - 1)), hi1 >>= 1;                                           \
+            VP = (VP >> 1) | TOP, VN >>= 1;                                                           \
+        }                                                                                             \
+        const WT T0 = (WT)0 - (((BW0) >> (R)) & (WT)1);                                               \
+        const WT T1 = (WT)0 - (((BW1) >> (R)) & (WT)1);                                               \
+        const WT Eq = ~((lo0 ^ T0) | (lo1 ^ T1));                                                     \
+        const WT D0 = ((((Eq & VP) + VP) ^ VP) | Eq) | VN;                                            \
+        const WT HP = VN | ~(D0 | VP);                                                                \
+        const WT HN = VP & D0;                                                                        \
+        if (SLIDE)                                                                                    \
+            S += 1 - (int)(D0 >> (W - 1));                                                            \
+        else                                                                                          \
+            S += (int)(HP >> (W - 1)) - (int)(HN >> (W - 1));                                         \
+        const WT X = (HP << 1) | (WT)1;                                                               \
+        VP = (HN << 1) | ~(D0 | X);                                                                   \
+        VN = D0 & X;                                                                                  \
+    }
+
+    // columns 1..C: the window still sits on rows 1..W
+    {
+        const WT b0 = BLK(B0, 0), b1 = BLK(B1, 0);
+        const int c1 = nn < C ? nn : C;
+        for (int r = 0; r < c1; r++) NW_BAND_COLUMN(false, b0, b1, r)
+    }
+    // columns C+1..n: slide one row per column; the reservoir's upper word is refilled every W slides
+#pragma unroll
+    for (int bq = 0; bq < NBLK; bq++) {
+        const WT b0 = BLK(B0, bq), b1 = BLK(B1, bq);
+        const int r0 = bq == 0 ? C : 0;
+        int rend = nn - W * bq;
+        rend = rend > W ? W : rend;
+        for (int r = r0; r < rend; r++) {
+            if (r == C) hi0 = BLK(A0, bq + 1), hi1 = BLK(A1, bq + 1); /* wave-uniform */
+            NW_BAND_COLUMN(true, b0, b1, r)
+        }
+    }
+#undef NW_BAND_COLUMN
+#undef BLK
+    const int top = nn > C - 1 ? nn - (C - 1) : 1; /* window top row of the last column */
+    const int bstar = m - top;                     /* bit of row m */
+    if (bstar < 0 || bstar > W - 1) return -1;
+    const WT above = bstar == W - 1 ? (WT)0 : (~(WT)0 << (bstar + 1));
+    const int up = W == 32 ? __popc((uint32_t)(VP & above)) : __popcll((u64)(VP & above));
+    const int dn = W == 32 ? __popc((uint32_t)(VN & above)) : __popcll((u64)(VN & above));
+    const int result = S - up + dn;
+    return result <= C - 1 ? result : -1; /* proven exact only up to W/2 - 1 */
+}
+
+template <int ND, int FIRSTW> /* plane dwords per string: 4 * w4; FIRSTW = 32 or 64: the first window tried */
 __global__ __launch_bounds__(ASM_BLOCK) void nw_banded_kernel(const uint4* __restrict__ planes,
                                                               const uint32_t* __restrict__ lens, long n, int w4,
-                                                              int32_t* __restrict__ out) {
+                                                              OutMap out) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t ln = lens[i];
     const int m = (int)(ln & 0xffffu), nn = (int)(ln >> 16);
-    uint32_t A0[ND + 1], A1[ND + 1], B0[ND], B1[ND];
+    uint32_t A0[ND + 2], A1[ND + 2], B0[ND], B1[ND];
 #pragma unroll
     for (int g = 0; g < ND / 4; g++) {
         uint4 q;
@@ -852,61 +976,13 @@ __global__ __launch_bounds__(ASM_BLOCK) void nw_banded_kernel(const uint4* __res
         q = planes[((long)3 * w4 + g) * n + i];
         B1[4 * g] = q.x, B1[4 * g + 1] = q.y, B1[4 * g + 2] = q.z, B1[4 * g + 3] = q.w;
     }
-    A0[ND] = A1[ND] = 0u;
+    A0[ND] = A1[ND] = A0[ND + 1] = A1[ND + 1] = 0u;
 
-    uint32_t VP = ~0u, VN = 0u; /* column 0: D[i][0] = i */
-    int S = 32;                 /* D[bottom row of the window][column] */
-    uint32_t lo0 = A0[0], lo1 = A1[0], hi0 = 0u, hi1 = 0u;
-
-#define NW_BAND_COLUMN(SLIDE, BDW0, BDW1, R)                                                         \
-    {                                                                                                 \
-        if (SLIDE) {                                                                                  \
-            lo0 = __builtin_amdgcn_alignbit(hi0, lo0, 1), hi0 >>= 1;                                  \
-            lo1 = __builtin_amdgcn_alignbit(hi1, lo1, 1), hi1 >>= 1;                                  \
-            VP = (VP >> 1) | 0x80000000u, VN >>= 1;                                                   \
-        }                                                                                             \
-        const uint32_t T0 = (uint32_t)__builtin_amdgcn_sbfe((int)(BDW0), (R), 1);                     \
-        const uint32_t T1 = (uint32_t)__builtin_amdgcn_sbfe((int)(BDW1), (R), 1);                     \
-        const uint32_t Eq = ~((lo0 ^ T0) | (lo1 ^ T1));                                               \
-        const uint32_t D0 = ((((Eq & VP) + VP) ^ VP) | Eq) | VN;                                      \
-        const uint32_t HP = VN | ~(D0 | VP);                                                          \
-        const uint32_t HN = VP & D0;                                                                  \
-        if (SLIDE)                                                                                    \
-            S += 1 - (int)(D0 >> 31);                                                                 \
-        else                                                                                          \
-            S += (int)(HP >> 31) - (int)(HN >> 31);                                                   \
-        const uint32_t X = (HP << 1) | 1u;                                                            \
-        VP = (HN << 1) | ~(D0 | X);                                                                   \
-        VN = D0 & X;                                                                                  \
-    }
-
-    // columns 1..16: the window still sits on rows 1..32
-    {
-        const int c1 = nn < NW_BAND_C ? nn : NW_BAND_C;
-        for (int r = 0; r < c1; r++) NW_BAND_COLUMN(false, B0[0], B1[0], r)
-    }
-    // columns 17..n: slide one row per column; the reservoir's upper dword is refilled every 32 slides
-#pragma unroll
-    for (int bq = 0; bq < ND; bq++) {
-        const int r0 = bq == 0 ? NW_BAND_C : 0;
-        int rend = nn - 32 * bq;
-        rend = rend > 32 ? 32 : rend;
-        for (int r = r0; r < rend; r++) {
-            if (r == 16) hi0 = A0[bq + 1], hi1 = A1[bq + 1]; /* wave-uniform */
-            NW_BAND_COLUMN(true, B0[bq], B1[bq], r)
-        }
-    }
-#undef NW_BAND_COLUMN
-
-    const int top = nn > NW_BAND_C - 1 ? nn - (NW_BAND_C - 1) : 1; /* window top row of the last column */
-    const int bstar = m - top;                                     /* bit of row m */
     int result = -1;
-    if (bstar >= 0 && bstar <= 31) {
-        const uint32_t above = bstar == 31 ? 0u : (~0u << (bstar + 1));
-        result = S - __popc(VP & above) + __popc(VN & above);
-    }
-    if (result < 0 || result > NW_BAND_KMAX) {
-        // outside the proven band: full-height sweep for this lane
+    if (FIRSTW == 32) result = nw_band<ND, 32>(A0, A1, B0, B1, m, nn);
+    if (result < 0) result = nw_band<ND, 64>(A0, A1, B0, B1, m, nn);
+    if (result < 0) {
+        // outside both proven bands: full-height sweep for this lane
         constexpr int W64 = ND / 2;
         VW<W64> a0, a1, b0, b1;
 #pragma unroll
@@ -918,7 +994,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void nw_banded_kernel(const uint4* __res
         }
         result = nw_unit_full<W64>(a0, a1, b0, b1, m, nn);
     }
-    out[i] = result;
+    out.put(i, result);
 }
 
 // accuracy counters (benchmark_utils.h:249-255).  A single hot word saturates at ~88 atomics/us on this chip

@@ -50,7 +50,7 @@ ASM_DEV int lane_read(int v, int lane /* wave-uniform */) {
 template <int W64>
 __global__ __launch_bounds__(ASM_BLOCK) void leap_wave_kernel(const uint4* __restrict__ planes,
                                                               const uint32_t* __restrict__ lens, long n, int w4,
-                                                              int k, int32_t* __restrict__ out) {
+                                                              int k, OutMap out) {
     const int t = threadIdx.x & 63;
     const long wave0 = __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void leap_wave_kernel(const uint4* __res
                 }
             }
         }
-        if (t == 0) out[i] = result;
+        if (t == 0) out.put(i, result);
     }
 }
 
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void leap_wave_kernel(const uint4* __res
 // --------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(ASM_BLOCK) void greedy_wave_kernel(const uint4* __restrict__ planes,
                                                                 const uint32_t* __restrict__ lens, long n, int w4,
-                                                                int k, GreedyArgs args, int32_t* __restrict__ out) {
+                                                                int k, GreedyArgs args, OutMap out) {
     const int t = threadIdx.x & 63;
     const long wave0 = __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_wave_kernel(const uint4* __r
                 const int hcf = x * distance;
                 cost += sw_f + (hcf > 0 ? hcf : 0);
             }
-            out[i] = cost;
+            out.put(i, cost);
         }
     }
 }

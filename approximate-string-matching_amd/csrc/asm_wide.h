@@ -23,7 +23,7 @@ template <int W64>
 __global__ __launch_bounds__(ASM_WIDE_THREADS) void leap_wide_kernel(const uint4* __restrict__ planes,
                                                                      const uint32_t* __restrict__ lens, long n,
                                                                      int w4, int k, int x, int o, int ext,
-                                                                     int32_t* __restrict__ out) {
+                                                                     OutMap out) {
     __shared__ int s_end[ASM_WIDE_RING][ASM_WIDE_THREADS + 2];
     __shared__ int s_ip[ASM_WIDE_RING][ASM_WIDE_THREADS + 2];
     __shared__ int s_dp[ASM_WIDE_RING][ASM_WIDE_THREADS + 2];
@@ -108,13 +108,13 @@ __global__ __launch_bounds__(ASM_WIDE_THREADS) void leap_wide_kernel(const uint4
                 }
             }
         }
-        if (t == 0) out[i] = result;
+        if (t == 0) out.put(i, result);
         __syncthreads(); /* ring is re-initialised by the next pair */
     }
 }
 
 static inline void launch_leap_wide(hipStream_t stream, const uint4* planes, const uint32_t* lens, int64_t n, int w4,
-                                    int k, int x, int o, int e, int32_t* out) {
+                                    int k, int x, int o, int e, OutMap out) {
     int64_t blocks = n < 256 * 32 ? n : 256 * 32;
     const int maxw = w4 * 2;
     if (maxw <= 2)
@@ -137,7 +137,7 @@ static inline void launch_leap_wide(hipStream_t stream, const uint4* planes, con
 __global__ __launch_bounds__(ASM_WIDE_THREADS) void greedy_wide_kernel(const uint4* __restrict__ planes,
                                                                        const uint32_t* __restrict__ lens, long n,
                                                                        int w4, int k, GreedyArgs args,
-                                                                       int32_t* __restrict__ out) {
+                                                                       OutMap out) {
     __shared__ double s_heur[ASM_WIDE_THREADS];
     __shared__ int s_leap[ASM_WIDE_THREADS];
     __shared__ int s_sp[ASM_WIDE_THREADS], s_len[ASM_WIDE_THREADS], s_cost[ASM_WIDE_THREADS];
@@ -242,14 +242,14 @@ __global__ __launch_bounds__(ASM_WIDE_THREADS) void greedy_wide_kernel(const uin
                 const int hc = x * distance;
                 cost += sw_f + (hc > 0 ? hc : 0);
             }
-            out[i] = cost;
+            out.put(i, cost);
         }
         __syncthreads();
     }
 }
 
 static inline void launch_greedy_wide(hipStream_t stream, const uint4* planes, const uint32_t* lens, int64_t n, int w4,
-                                      int k, const GreedyArgs& ga, int32_t* out) {
+                                      int k, const GreedyArgs& ga, OutMap out) {
     int64_t blocks = n < 256 * 32 ? n : 256 * 32;
     hipLaunchKernelGGL(greedy_wide_kernel, dim3((unsigned)blocks), dim3(ASM_WIDE_THREADS), 0, stream, planes, lens, (long)n,
                        w4, k, ga, out);
@@ -268,7 +268,7 @@ static inline void launch_greedy_wide(hipStream_t stream, const uint4* planes, c
 template <int W64, int MAXROWS>
 __global__ __launch_bounds__(64) void nw_affine_kernel(const uint4* __restrict__ planes,
                                                        const uint32_t* __restrict__ lens, long n, int w4, int x,
-                                                       int o, int e, int32_t* __restrict__ out) {
+                                                       int o, int e, OutMap out) {
     __shared__ uint32_t s_bound[MAXROWS + 1][64];
     const int t = threadIdx.x;
     const long i = (long)blockIdx.x * 64 + t;
@@ -342,11 +342,11 @@ __global__ __launch_bounds__(64) void nw_affine_kernel(const uint4* __restrict__
                 if (jj == want) result = H[jj];
         }
     }
-    out[i] = result;
+    out.put(i, result);
 }
 
 static inline void launch_nw_affine(hipStream_t stream, const uint4* planes, const uint32_t* lens, int64_t n, int w4,
-                                    int maxlen, int x, int o, int e, int32_t* out) {
+                                    int maxlen, int x, int o, int e, OutMap out) {
     const dim3 g((unsigned)((n + 63) / 64)), t(64);
     if (maxlen <= 128)
         hipLaunchKernelGGL((nw_affine_kernel<2, 128>), g, t, 0, stream, planes, lens, (long)n, w4, x, o, e, out);

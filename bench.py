@@ -66,12 +66,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    if os.environ.get("ASM_DIST_BACKEND", "nccl") != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()  # rehearsal: several ranks share the one visible GPU
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # backend "nccl" IS RCCL on ROCm; ASM_DIST_BACKEND=gloo only to rehearse the N>1 code path on a one-GPU box
+        backend = os.environ.get("ASM_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     cfg, n_default, params = asm.workload(args.workload)
     n = args.pairs or min(n_default, 1_000_000)
