@@ -120,6 +120,8 @@ def load_library() -> ctypes.CDLL:
         "asm_batch_pack_async": (i32, [vp, vp]),
         "asm_align_batch_async": (i32, [vp, vp, i32, c.POINTER(Params), vp]),
         "asm_align_batch": (i32, [vp, i32, i64, vp, vp, vp, vp, c.POINTER(Params), i32, vp]),
+        "asm_greedy_cigar_batch_async": (i32, [vp, vp, c.POINTER(Params), vp, vp, i32, vp]),
+        "asm_cigar_format": (i32, [vp, i32, i32, vp, c.c_size_t]),
         "asm_count_equal_async": (i32, [vp, vp, vp, i64, vp]),
         "asm_accuracy_async": (i32, [vp, vp, vp, vp, vp, i64, vp]),
         "asm_run_benchmark_async": (i32, [vp, vp, c.POINTER(Params), i32, vp, vp, vp, vp, vp]),
@@ -348,6 +350,27 @@ class Engine:
         self._chk(self.lib.asm_align_batch(self.h, aligner, hb.n, reads.ctypes.data, ro.ctypes.data, refs.ctypes.data,
                                            fo.ctypes.data, ctypes.byref(params), greedy_mode, out.ctypes.data))
         return out
+
+    def greedy_with_cigar(self, batch: DeviceBatch, params: Params, cap: int = 48):
+        """-> (costs int32[n], CIGAR strings) — hurdle_matrix::get_cost / get_CIGAR for every pair of the batch."""
+        n = batch.n
+        d_pen, d_ops, d_nops = self.malloc(4 * max(n, 1)), self.malloc(2 * cap * max(n, 1)), self.malloc(max(n, 1))
+        try:
+            self._chk(self.lib.asm_greedy_cigar_batch_async(self.h, batch.ptr, ctypes.byref(params), d_pen, d_ops, cap,
+                                                            d_nops))
+            costs = self.to_host(d_pen, n)
+            ops = self.to_host(d_ops, n * cap, np.uint16).reshape(n, cap)
+            nops = self.to_host(d_nops, n, np.uint8)
+        finally:
+            for p in (d_pen, d_ops, d_nops):
+                self.free(p)
+        letters = np.array(list("MID?"))
+        cigars = []
+        for i in range(n):
+            k = min(int(nops[i]), cap)
+            row = ops[i, :k]
+            cigars.append("".join(f"{int(v) >> 2}{letters[int(v) & 3]}" for v in row))
+        return costs, cigars, nops
 
     def count_equal_async(self, d_a: int, d_b: int, n: int, d_count: int) -> None:
         self._chk(self.lib.asm_count_equal_async(self.h, d_a, d_b, n, d_count))

@@ -122,5 +122,29 @@ ASM_DEV V128 v_low_ones(int len) {
 struct OutMap {
     int32_t* out;
     const uint32_t* order;
-    ASM_DEV void put(long i, int v) const { out[order ? (long)order[i] : i] = v; }
+    ASM_DEV long index(long i) const { return order ? (long)order[i] : i; }
+    ASM_DEV void put(long i, int v) const { out[index(i)] = v; }
+};
+
+// Optional CIGAR output of the Greedy kernels (hurdle_matrix::_update_CIGAR, GASMA/hurdle_matrix.h:238-251): per pair
+// a row of `cap` uint16 entries (count << 2 | op, op 0 = 'M', 1 = 'I', 2 = 'D') and the number of entries produced
+// (which may exceed cap: the row is then truncated and the caller sees nops > cap).  ops == null disables it.
+struct CigarSink {
+    uint16_t* ops;
+    uint8_t* nops;
+    int cap;
+    ASM_DEV bool on() const { return ops != nullptr; }
+    ASM_DEV void emit(long pair, int& cnt, int count, int op) const {
+        if (cnt < cap) ops[pair * cap + cnt] = (uint16_t)((count << 2) | op);
+        cnt++;
+    }
+    // lane switch, then the run of (mis)matches — the two appends of _update_CIGAR
+    ASM_DEV void step(long pair, int& cnt, int from_lane, int to_lane, int run) const {
+        if (to_lane < from_lane)
+            emit(pair, cnt, from_lane - to_lane, 1);
+        else if (to_lane > from_lane)
+            emit(pair, cnt, to_lane - from_lane, 2);
+        if (run > 0) emit(pair, cnt, run, 0);
+    }
+    ASM_DEV void finish(long pair, int cnt) const { nops[pair] = (uint8_t)(cnt > 255 ? 255 : cnt); }
 };

@@ -97,12 +97,12 @@ static hipError_t launch_persistent(asm_handle* h, Kern kern, int64_t n, Args...
 }
 
 template <int K>
-static hipError_t launch_greedy(asm_handle* h, const asm_bucket& b, const GreedyArgs& ga, OutMap out) {
+static hipError_t launch_greedy(asm_handle* h, const asm_bucket& b, const GreedyArgs& ga, OutMap out, CigarSink cig) {
     if (h->persist)
         return launch_persistent(h, greedy_persist_kernel<K>, b.n, (const uint4*)b.planes, (const uint32_t*)b.lens,
-                                 (long)b.n, b.w4, ga, out, h->refill_greedy);
+                                 (long)b.n, b.w4, ga, out, cig, h->refill_greedy);
     hipLaunchKernelGGL(greedy_kernel<K>, dim3(grid_for(b.n)), dim3(ASM_BLOCK), 0, h->stream, b.planes, b.lens, (long)b.n,
-                       b.w4, ga, out);
+                       b.w4, ga, out, cig);
     return hipGetLastError();
 }
 
@@ -602,7 +602,8 @@ static int check_params(asm_handle* h, int aligner, const asm_params* p) {
 }
 
 /* one aligner over one width class */
-static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const asm_params* p, OutMap out) {
+static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const asm_params* p, OutMap out,
+                        CigarSink cig = CigarSink{nullptr, nullptr, 0}) {
     if (b.n == 0) return ASM_OK;
     const bool unit = (p->x == 1 && p->o == 1 && p->e == 1);
     const uint4* planes = b.planes;
@@ -614,17 +615,17 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
         ga.sig_mismatch = log(p->p_mismatch / 0.25);
         ga.sig_indel = log(p->p_indel / 2 / 0.25);
         switch (p->k) {
-            case 1: HIPCHK(h, launch_greedy<1>(h, b, ga, out)); break;
-            case 2: HIPCHK(h, launch_greedy<2>(h, b, ga, out)); break;
-            case 3: HIPCHK(h, launch_greedy<3>(h, b, ga, out)); break;
-            case 4: HIPCHK(h, launch_greedy<4>(h, b, ga, out)); break;
-            case 5: HIPCHK(h, launch_greedy<5>(h, b, ga, out)); break;
+            case 1: HIPCHK(h, launch_greedy<1>(h, b, ga, out, cig)); break;
+            case 2: HIPCHK(h, launch_greedy<2>(h, b, ga, out, cig)); break;
+            case 3: HIPCHK(h, launch_greedy<3>(h, b, ga, out, cig)); break;
+            case 4: HIPCHK(h, launch_greedy<4>(h, b, ga, out, cig)); break;
+            case 5: HIPCHK(h, launch_greedy<5>(h, b, ga, out, cig)); break;
             default:
                 if (p->k <= ASM_WAVE_MAX_K && h->wave_kernels && (long)p->o + 62L * p->e < 16000L)
                     launch_wave_per_pair(h->stream, greedy_wave_kernel, b.n, h->num_cus, planes, lens, (long)b.n, b.w4,
-                                         (int)p->k, ga, out);
+                                         (int)p->k, ga, out, cig);
                 else
-                    launch_greedy_wide(h->stream, planes, lens, b.n, b.w4, p->k, ga, out);
+                    launch_greedy_wide(h->stream, planes, lens, b.n, b.w4, p->k, ga, out, cig);
                 break;
         }
     } else if (aligner == ASM_LEAP) {
@@ -691,6 +692,37 @@ int asm_align_batch_async(asm_handle* h, const asm_batch* b, int aligner, const 
         rc = align_bucket(h, b->bk[q], aligner, p, out);
     }
     return rc;
+}
+
+int asm_greedy_cigar_batch_async(asm_handle* h, const asm_batch* b, const asm_params* p, int32_t* d_penalties,
+                                 uint16_t* d_ops, int cap, uint8_t* d_nops) {
+    if (!h || !b || !d_penalties || !d_ops || !d_nops || cap < 1)
+        return fail(h, ASM_EINVAL, "asm_greedy_cigar_batch_async: bad argument");
+    int rc = check_params(h, ASM_GREEDY, p);
+    if (rc) return rc;
+    if (b->n == 0) return ASM_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    for (int q = 0; q < b->nb && !rc; q++) {
+        OutMap out;
+        out.out = d_penalties;
+        out.order = b->bk[q].order;
+        rc = align_bucket(h, b->bk[q], ASM_GREEDY, p, out, CigarSink{d_ops, d_nops, cap});
+    }
+    return rc;
+}
+
+int asm_cigar_format(const uint16_t* ops, int nops, int cap, char* out, size_t out_cap) {
+    if (!ops || !out || out_cap == 0) return ASM_EINVAL;
+    size_t len = 0;
+    out[0] = 0;
+    const int cnt = nops < cap ? nops : cap;
+    for (int i = 0; i < cnt; i++) {
+        const char op = "MID?"[ops[i] & 3];
+        const int w = snprintf(out + len, out_cap - len, "%d%c", (int)(ops[i] >> 2), op);
+        if (w < 0 || len + (size_t)w >= out_cap) return ASM_EINVAL;
+        len += (size_t)w;
+    }
+    return nops > cap ? ASM_EUNSUPPORTED : ASM_OK; /* truncated row */
 }
 
 int asm_align_batch(asm_handle* h, int aligner, int64_t n, const char* reads, const uint32_t* read_off, const char* refs,

@@ -216,10 +216,12 @@ ASM_DEV V128 greedy_lane_vector(V128 A0, V128 A1, V128 B0, V128 B1, int lane) {
 template <int K>
 __global__ __launch_bounds__(ASM_BLOCK) void greedy_kernel(const uint4* __restrict__ planes,
                                                            const uint32_t* __restrict__ lens, long n, int w4,
-                                                           GreedyArgs args, OutMap out) {
+                                                           GreedyArgs args, OutMap out, CigarSink cig) {
     constexpr int NL = 2 * K + 1;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const long pair = out.index(i);
+    int ncig = 0;
     const V128 A0 = v_from_uint4(planes[((long)0 * w4) * n + i]);
     const V128 A1 = v_from_uint4(planes[((long)1 * w4) * n + i]);
     const V128 B0 = v_from_uint4(planes[((long)2 * w4) * n + i]);
@@ -334,6 +336,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_kernel(const uint4* __restri
         }
         // ---- _step commit (hurdle_matrix.h:411-433) ----
         cost += ch_cost;
+        if (cig.on()) cig.step(pair, ncig, cur_lane, ch, ch_sp + ch_len - (cur_col + fwd_col(cur_lane, ch)));
         cur_lane = ch;
         cur_col = ch_sp + ch_len;
         if (cur_col >= lane_destination(m, nn, ch)) break;
@@ -347,7 +350,9 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_kernel(const uint4* __restri
         const int distance = v_pop_between(dv, cur_col + fwd_col(cur_lane, dest_lane), dest_col);
         const int hc = x * distance;
         cost += sw_f + (hc > 0 ? hc : 0);
+        if (cig.on()) cig.step(pair, ncig, cur_lane, dest_lane, distance); /* the hurdle count, not the distance (:589) */
     }
+    if (cig.on()) cig.finish(pair, ncig);
     out.put(i, cost);
 }
 
@@ -386,14 +391,14 @@ template <int K>
 __global__ __launch_bounds__(ASM_BLOCK) void greedy_persist_kernel(const uint4* __restrict__ planes,
                                                                    const uint32_t* __restrict__ lens, long n, int w4,
                                                                    GreedyArgs args, OutMap out,
-                                                                   int refill_min) {
+                                                                   CigarSink cig, int refill_min) {
     constexpr int NL = 2 * K + 1;
     const int x = args.x, o = args.o, e = args.e;
     V128 lo_[NL], lf_[NL];
     int sp[NL], len[NL], nsw[NL], dst[NL], sw[NL], nh[NL];
     V128 dest_vec = v_make(0, 0);
-    int m = 0, nn = 0, dest_lane = 0, cur_lane = 0, cur_col = 0, cost = 0, guard = 0;
-    long idx = -1;
+    int m = 0, nn = 0, dest_lane = 0, cur_lane = 0, cur_col = 0, cost = 0, guard = 0, ncig = 0;
+    long idx = -1, pair = 0;
     bool active = false, finished = true, exhausted = false;
     WaveQueue wq;
     wq.init(n);
@@ -416,7 +421,9 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_persist_kernel(const uint4* 
                     const int distance = v_pop_between(dest_vec, cur_col + fwd_col(cur_lane, dest_lane), dest_col);
                     const int hc = x * distance;
                     cost += sw_f + (hc > 0 ? hc : 0);
+                    if (cig.on()) cig.step(pair, ncig, cur_lane, dest_lane, distance);
                 }
+                if (cig.on()) cig.finish(pair, ncig);
                 out.put(idx, cost);
             }
             const long got = wq.pull(need);
@@ -446,7 +453,8 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_persist_kernel(const uint4* 
                     dst[j] = lane_destination(m, nn, lane);
                 }
                 dest_vec = greedy_lane_vector(A0, A1, B0, B1, dest_lane); /* may lie outside the band (G13) */
-                cur_lane = 0, cur_col = 0, cost = 0, guard = 0;
+                cur_lane = 0, cur_col = 0, cost = 0, guard = 0, ncig = 0;
+                pair = out.index(idx);
                 finished = false;
             }
         }
@@ -517,6 +525,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_persist_kernel(const uint4* 
                 }
                 // ---- _step commit (hurdle_matrix.h:411-433) ----
                 cost += ch_cost;
+                if (cig.on()) cig.step(pair, ncig, cur_lane, ch, ch_sp + ch_len - (cur_col + fwd_col(cur_lane, ch)));
                 cur_lane = ch;
                 cur_col = ch_sp + ch_len;
                 if (cur_col >= lane_destination(m, nn, ch)) finished = true;

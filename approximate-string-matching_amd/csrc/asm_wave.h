@@ -117,7 +117,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void leap_wave_kernel(const uint4* __res
 // --------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(ASM_BLOCK) void greedy_wave_kernel(const uint4* __restrict__ planes,
                                                                 const uint32_t* __restrict__ lens, long n, int w4,
-                                                                int k, GreedyArgs args, OutMap out) {
+                                                                int k, GreedyArgs args, OutMap out, CigarSink cig) {
     const int t = threadIdx.x & 63;
     const long wave0 = __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
@@ -139,7 +139,8 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_wave_kernel(const uint4* __r
         const V128 lf_ = v_flip_short_hurdles1(lo_);
         const int dst = lane_destination(m, nn, lane);
         int sp = -1, len = 0, nsw = 128;
-        int cur_lane = 0, cur_col = 0, cost = 0;
+        int cur_lane = 0, cur_col = 0, cost = 0, ncig = 0;
+        const long pair = out.index(i);
         for (int guard = 0; guard < 4 * 128; guard++) {
             // ---- _update_highway_list, one band lane per wave lane ----
             bool reach = false;
@@ -214,8 +215,10 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_wave_kernel(const uint4* __r
             }
             // ---- _step commit (hurdle_matrix.h:411-433) ----
             cost += lane_read(sw + hc, ct);
+            const int new_col = lane_read(sp, ct) + lane_read(len, ct);
+            if (cig.on() && t == 0) cig.step(pair, ncig, cur_lane, ct - k, new_col - (cur_col + fwd_col(cur_lane, ct - k)));
             cur_lane = ct - k;
-            cur_col = lane_read(sp, ct) + lane_read(len, ct);
+            cur_col = new_col;
             if (cur_col >= lane_destination(m, nn, cur_lane)) break;
         }
         if (t == 0) {
@@ -227,7 +230,9 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_wave_kernel(const uint4* __r
                 const int distance = v_pop_between(dv, cur_col + fwd_col(cur_lane, dest_lane), dest_col);
                 const int hcf = x * distance;
                 cost += sw_f + (hcf > 0 ? hcf : 0);
+                if (cig.on()) cig.step(pair, ncig, cur_lane, dest_lane, distance);
             }
+            if (cig.on()) cig.finish(pair, ncig);
             out.put(i, cost);
         }
     }

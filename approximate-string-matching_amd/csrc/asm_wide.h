@@ -137,7 +137,7 @@ static inline void launch_leap_wide(hipStream_t stream, const uint4* planes, con
 __global__ __launch_bounds__(ASM_WIDE_THREADS) void greedy_wide_kernel(const uint4* __restrict__ planes,
                                                                        const uint32_t* __restrict__ lens, long n,
                                                                        int w4, int k, GreedyArgs args,
-                                                                       OutMap out) {
+                                                                       OutMap out, CigarSink cig) {
     __shared__ double s_heur[ASM_WIDE_THREADS];
     __shared__ int s_leap[ASM_WIDE_THREADS];
     __shared__ int s_sp[ASM_WIDE_THREADS], s_len[ASM_WIDE_THREADS], s_cost[ASM_WIDE_THREADS];
@@ -162,7 +162,8 @@ __global__ __launch_bounds__(ASM_WIDE_THREADS) void greedy_wide_kernel(const uin
         const V128 lf_ = v_flip_short_hurdles1(lo_);
         int sp = -1, len = 0, nsw = 128;
         const int dst = lane_destination(m, nn, lane);
-        int cur_lane = 0, cur_col = 0, cost = 0;
+        int cur_lane = 0, cur_col = 0, cost = 0, ncig = 0;
+        const long pair = out.index(i);
         for (int guard = 0; guard < 4 * 128; guard++) {
             int reach = 0, sw = 0, nh = 0;
             if (active) {
@@ -227,6 +228,8 @@ __global__ __launch_bounds__(ASM_WIDE_THREADS) void greedy_wide_kernel(const uin
             }
             const int ch = ct - k;
             cost += s_cost[ct];
+            if (cig.on() && t == 0)
+                cig.step(pair, ncig, cur_lane, ch, s_sp[ct] + s_len[ct] - (cur_col + fwd_col(cur_lane, ch)));
             cur_lane = ch;
             cur_col = s_sp[ct] + s_len[ct];
             const bool done = cur_col >= lane_destination(m, nn, ch);
@@ -241,7 +244,9 @@ __global__ __launch_bounds__(ASM_WIDE_THREADS) void greedy_wide_kernel(const uin
                 const int distance = v_pop_between(dv, cur_col + fwd_col(cur_lane, dest_lane), dest_col);
                 const int hc = x * distance;
                 cost += sw_f + (hc > 0 ? hc : 0);
+                if (cig.on()) cig.step(pair, ncig, cur_lane, dest_lane, distance);
             }
+            if (cig.on()) cig.finish(pair, ncig);
             out.put(i, cost);
         }
         __syncthreads();
@@ -249,10 +254,10 @@ __global__ __launch_bounds__(ASM_WIDE_THREADS) void greedy_wide_kernel(const uin
 }
 
 static inline void launch_greedy_wide(hipStream_t stream, const uint4* planes, const uint32_t* lens, int64_t n, int w4,
-                                      int k, const GreedyArgs& ga, OutMap out) {
+                                      int k, const GreedyArgs& ga, OutMap out, CigarSink cig) {
     int64_t blocks = n < 256 * 32 ? n : 256 * 32;
     hipLaunchKernelGGL(greedy_wide_kernel, dim3((unsigned)blocks), dim3(ASM_WIDE_THREADS), 0, stream, planes, lens, (long)n,
-                       w4, k, ga, out);
+                       w4, k, ga, out, cig);
 }
 
 // --------------------------------------------------------------------------------------------------------

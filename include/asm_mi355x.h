@@ -117,6 +117,14 @@ int asm_batch_pack_async(asm_handle* h, asm_batch* b);
  * (hurdle_matrix.h:677). */
 int asm_align_batch_async(asm_handle* h, const asm_batch* b, int aligner, const asm_params* p,
                           int32_t* d_penalties);
+/* Greedy with its CIGAR (hurdle_matrix::get_CIGAR, hurdle_matrix.h:613; built by _update_CIGAR :238-251 — lane switches
+ * as nI / nD, runs of matches AND mismatches as nM, and the final hop's run is the hurdle count, :589).  d_ops = device
+ * uint16[n][cap], entry = count << 2 | op with op 0 'M', 1 'I', 2 'D'; d_nops = device uint8[n] = entries produced (a
+ * value above cap means the row was truncated).  Enqueue only. */
+int asm_greedy_cigar_batch_async(asm_handle* h, const asm_batch* b, const asm_params* p, int32_t* d_penalties,
+                                 uint16_t* d_ops, int cap, uint8_t* d_nops);
+/* Host helper: formats one encoded row as the reference's string ("22M1D50M1D28M"). */
+int asm_cigar_format(const uint16_t* ops, int nops, int cap, char* out, size_t out_cap);
 /* Convenience: host in, host out (upload + pack + align + copy back).  The reference-shaped call:
  * align(read, ref, k) for every pair of the batch. */
 int asm_align_batch(asm_handle* h, int aligner, int64_t n, const char* reads, const uint32_t* read_off,

@@ -193,3 +193,19 @@ def test_asm_bench_harness_prints_reference_block(asm, oracle, tmp_path):
         acc = lines[lines.index("[Accuracy] (percentage of alignments matching optimal penalty)") + 1:][:3]
         for line, (name, val) in zip(acc, want.items()):
             assert line == "=> %-16s | %.3f %%" % (name, val), (line, name, val)
+
+
+@pytest.mark.parametrize("wl,n,k,mode", [("C2", 20000, 3, 1), ("C2", 8000, 3, 0), ("C1", 5000, 2, 1), ("C3", 3000, 30, 1),
+                                         ("C5", 8000, 3, 1), ("C2", 3000, 10, 1), ("C2", 2000, 40, 1)])
+def test_greedy_cigar(asm, engine, oracle, wl, n, k, mode):
+    """hurdle_matrix::get_CIGAR on the device (narrow, wave-per-pair and workgroup-per-pair kernels), string for
+    string against the oracle — whose CIGARs are pinned to the compiled reference by tests/golden."""
+    cfg, _, _ = asm.workload(wl)
+    hb = asm.generate_pairs(cfg, 3, n)
+    want_cost, want_cig = oracle.greedy(hb, k=k, mode=mode, cigars=True)
+    batch = engine.upload(hb, mode)
+    cost, cig, nops = engine.greedy_with_cigar(batch, asm.Params.default(k=k), cap=64)
+    _check("cost", cost, want_cost, hb)
+    assert int(nops.max()) <= 64
+    bad = [i for i in range(n) if cig[i] != want_cig[i]]
+    assert not bad, (len(bad), bad[:3], cig[bad[0]], want_cig[bad[0]])
