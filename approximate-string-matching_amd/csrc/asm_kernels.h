@@ -50,6 +50,57 @@ ASM_DEV uint32_t swar_zero_bytes(uint32_t t) { /* bit 7 of each byte set iff tha
     return ~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t | 0x7f7f7f7fu);
 }
 
+// One thread converts its string out of the (swizzled) LDS staging buffer and stores its plane granules.
+template <int W4>
+ASM_DEV void pack_convert(const uint32_t* sb, uint32_t b0, int len, int w4, int s, const uint4* __restrict__ tails,
+                          long n, long pair, uint4* __restrict__ bplanes, long bn, long local) {
+    const int a0 = (int)(b0 >> 2);
+    const uint32_t sh = (b0 & 3u) * 8u;
+#pragma unroll
+    for (int g = 0; g < W4; g++) {
+        if (g < w4) {
+            uint32_t q0[4] = {0u, 0u, 0u, 0u}, q1[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const int cbase = g * 128 + w * 32;
+                if (cbase < len) {
+                    uint32_t d[9];
+#pragma unroll
+                    for (int q = 0; q < 9; q++) {
+                        const int a = a0 + (cbase >> 2) + q;
+                        d[q] = sb[a ^ (((a >> 5) & 7) << 2)];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        uint32_t ch = __builtin_amdgcn_alignbit(d[q + 1], d[q], sh);
+                        const int rem = len - (cbase + 4 * q);
+                        const uint32_t vm = rem >= 4 ? ~0u : (rem <= 0 ? 0u : (0xffffffffu >> (32 - 8 * rem)));
+                        ch &= vm;
+                        const uint32_t x = ch ^ 0x43434343u; /* 'C' */
+                        const uint32_t fC = swar_zero_bytes(x);
+                        const uint32_t fG = swar_zero_bytes(x ^ 0x04040404u); /* 'G' = 'C' ^ 0x04 */
+                        const uint32_t fT = swar_zero_bytes(x ^ 0x17171717u); /* 'T' = 'C' ^ 0x17 */
+                        /* gather the four byte flags (bits 7,15,23,31) into a nibble */
+                        q0[w] |= (((fC | fT) * 0x00204081u) >> 28) << (4 * q);
+                        q1[w] |= (((fG | fT) * 0x00204081u) >> 28) << (4 * q);
+                    }
+                }
+            }
+            uint4 v0 = make_uint4(q0[0], q0[1], q0[2], q0[3]);
+            uint4 v1 = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+            if (tails != nullptr && g == 0) {
+                const uint4 t0 = tails[(long)(2 * s) * n + pair], t1 = tails[(long)(2 * s + 1) * n + pair];
+                v0.x |= t0.x, v0.y |= t0.y, v0.z |= t0.z, v0.w |= t0.w;
+                v1.x |= t1.x, v1.y |= t1.y, v1.z |= t1.z, v1.w |= t1.w;
+            }
+            bplanes[((long)(2 * s) * w4 + g) * bn + local] = v0;
+            bplanes[((long)(2 * s + 1) * w4 + g) * bn + local] = v1;
+        }
+    }
+}
+
+#define PACK_NV (PACK_SB / 16 / ASM_BLOCK) /* staging vectors per thread when a string's bytes fit the buffer */
+
 template <int W4>
 __global__ __launch_bounds__(ASM_BLOCK) void pack_kernel(const char* __restrict__ reads,
                                                          const uint32_t* __restrict__ read_off,
@@ -60,12 +111,11 @@ __global__ __launch_bounds__(ASM_BLOCK) void pack_kernel(const char* __restrict_
                                                          long n, PackBuckets pb,
                                                          const uint32_t* __restrict__ pos /* pair -> slot, or null */) {
     __shared__ uint4 s_buf[PACK_SB / 16 + 4];
-    __shared__ uint32_t s_off[ASM_BLOCK + 1];
+    __shared__ uint32_t s_off[2][ASM_BLOCK + 1];
     const int t = threadIdx.x;
     const long p0 = (long)blockIdx.x * ASM_BLOCK;
     const int np = (n - p0) < ASM_BLOCK ? (int)(n - p0) : ASM_BLOCK;
     const uint32_t* sb = reinterpret_cast<const uint32_t*>(s_buf);
-    uint32_t my_len[2] = {0u, 0u};
     // where this thread's pair lives in the bucketed layout
     const long slot = (t < np) ? (pos ? (long)pos[p0 + t] : p0 + t) : 0;
     int bk = 0;
@@ -75,23 +125,61 @@ __global__ __launch_bounds__(ASM_BLOCK) void pack_kernel(const char* __restrict_
     const int w4 = pb.w4[bk];
     const long bn = pb.start[bk + 1] - pb.start[bk], local = slot - pb.start[bk];
     uint4* bplanes = planes + pb.plane_off[bk];
+
+    // both offset tables up front: one global round trip instead of two
+    s_off[0][t] = read_off[p0 + (t < np ? t : np)];
+    s_off[1][t] = ref_off[p0 + (t < np ? t : np)];
+    if (t == 0) s_off[0][ASM_BLOCK] = read_off[p0 + np], s_off[1][ASM_BLOCK] = ref_off[p0 + np];
+    __syncthreads();
+    const uint32_t oA0 = s_off[0][t], oA1 = s_off[0][t + 1], oB0 = s_off[1][t], oB1 = s_off[1][t + 1];
+    const uint32_t baseA = s_off[0][0] & ~15u, baseB = s_off[1][0] & ~15u;
+    const uint32_t bytesA = s_off[0][ASM_BLOCK] - baseA, bytesB = s_off[1][ASM_BLOCK] - baseB;
+    if (t < np) lens[slot] = (oA1 - oA0) | ((oB1 - oB0) << 16);
+
+    if (bytesA <= (uint32_t)PACK_SB && bytesB <= (uint32_t)PACK_SB) {
+        // Fast path (every string of the block fits the buffer): the refs' bytes are fetched into registers while the
+        // reads are being converted, so their HBM latency hides behind the SWAR work.
+        const int nvA = (int)((bytesA + 15u) >> 4), nvB = (int)((bytesB + 15u) >> 4);
+        const uint4* srcA = reinterpret_cast<const uint4*>(reads + baseA);
+        const uint4* srcB = reinterpret_cast<const uint4*>(refs + baseB);
+        for (int v = t; v < nvA; v += ASM_BLOCK) {
+            const int a = 4 * v;
+            s_buf[(a ^ (((a >> 5) & 7) << 2)) >> 2] = srcA[v];
+        }
+        uint4 rb[PACK_NV];
+#pragma unroll
+        for (int q = 0; q < PACK_NV; q++) {
+            const int v = t + q * ASM_BLOCK;
+            rb[q] = v < nvB ? srcB[v] : make_uint4(0u, 0u, 0u, 0u);
+        }
+        __syncthreads();
+        if (t < np) pack_convert<W4>(sb, oA0 - baseA, (int)(oA1 - oA0), w4, 0, tails, n, p0 + t, bplanes, bn, local);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PACK_NV; q++) {
+            const int v = t + q * ASM_BLOCK;
+            if (v < nvB) {
+                const int a = 4 * v;
+                s_buf[(a ^ (((a >> 5) & 7) << 2)) >> 2] = rb[q];
+            }
+        }
+        __syncthreads();
+        if (t < np) pack_convert<W4>(sb, oB0 - baseB, (int)(oB1 - oB0), w4, 1, tails, n, p0 + t, bplanes, bn, local);
+        return;
+    }
+    // General path: stage whole pairs in rounds that fit the buffer.
 #pragma unroll 1
     for (int s = 0; s < 2; s++) {
         const char* str = s ? refs : reads;
-        const uint32_t* off = s ? ref_off : read_off;
-        __syncthreads();
-        s_off[t] = off[p0 + (t < np ? t : np)];
-        if (t == 0) s_off[ASM_BLOCK] = off[p0 + np];
-        __syncthreads();
-        const uint32_t o0 = s_off[t], o1 = s_off[t + 1];
+        const uint32_t o0 = s ? oB0 : oA0, o1 = s ? oB1 : oA1;
         const int len = (int)(o1 - o0);
-        my_len[s] = (uint32_t)len;
         int ps = 0;
         while (ps < np) { /* uniform across the workgroup */
-            const uint32_t base = s_off[ps] & ~15u;
+            __syncthreads();
+            const uint32_t base = s_off[s][ps] & ~15u;
             const int fits = (t >= ps && t < np && (o1 - base) <= (uint32_t)PACK_SB) ? 1 : 0;
             const int pe = ps + __syncthreads_count(fits); /* offsets are monotone: the fitting pairs are [ps, pe) */
-            const uint32_t hi = s_off[pe];
+            const uint32_t hi = s_off[s][pe];
             const int nvec = (int)((hi - base + 15u) >> 4);
             const uint4* src = reinterpret_cast<const uint4*>(str + base);
             for (int v = t; v < nvec; v += ASM_BLOCK) {
@@ -99,57 +187,10 @@ __global__ __launch_bounds__(ASM_BLOCK) void pack_kernel(const char* __restrict_
                 s_buf[(a ^ (((a >> 5) & 7) << 2)) >> 2] = src[v];
             }
             __syncthreads();
-            if (t >= ps && t < pe) {
-                const uint32_t b0 = o0 - base;
-                const int a0 = (int)(b0 >> 2);
-                const uint32_t sh = (b0 & 3u) * 8u;
-#pragma unroll
-                for (int g = 0; g < W4; g++) {
-                    if (g < w4) {
-                        uint32_t q0[4] = {0u, 0u, 0u, 0u}, q1[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-                        for (int w = 0; w < 4; w++) {
-                            const int cbase = g * 128 + w * 32;
-                            if (cbase < len) {
-                                uint32_t d[9];
-#pragma unroll
-                                for (int q = 0; q < 9; q++) {
-                                    const int a = a0 + (cbase >> 2) + q;
-                                    d[q] = sb[a ^ (((a >> 5) & 7) << 2)];
-                                }
-#pragma unroll
-                                for (int q = 0; q < 8; q++) {
-                                    uint32_t ch = __builtin_amdgcn_alignbit(d[q + 1], d[q], sh);
-                                    const int rem = len - (cbase + 4 * q);
-                                    const uint32_t vm = rem >= 4 ? ~0u : (rem <= 0 ? 0u : (0xffffffffu >> (32 - 8 * rem)));
-                                    ch &= vm;
-                                    const uint32_t x = ch ^ 0x43434343u; /* 'C' */
-                                    const uint32_t fC = swar_zero_bytes(x);
-                                    const uint32_t fG = swar_zero_bytes(x ^ 0x04040404u); /* 'G' = 'C' ^ 0x04 */
-                                    const uint32_t fT = swar_zero_bytes(x ^ 0x17171717u); /* 'T' = 'C' ^ 0x17 */
-                                    /* gather the four byte flags (bits 7,15,23,31) into a nibble */
-                                    q0[w] |= (((fC | fT) * 0x00204081u) >> 28) << (4 * q);
-                                    q1[w] |= (((fG | fT) * 0x00204081u) >> 28) << (4 * q);
-                                }
-                            }
-                        }
-                        uint4 v0 = make_uint4(q0[0], q0[1], q0[2], q0[3]);
-                        uint4 v1 = make_uint4(q1[0], q1[1], q1[2], q1[3]);
-                        if (tails != nullptr && g == 0) {
-                            const uint4 t0 = tails[(long)(2 * s) * n + p0 + t], t1 = tails[(long)(2 * s + 1) * n + p0 + t];
-                            v0.x |= t0.x, v0.y |= t0.y, v0.z |= t0.z, v0.w |= t0.w;
-                            v1.x |= t1.x, v1.y |= t1.y, v1.z |= t1.z, v1.w |= t1.w;
-                        }
-                        bplanes[((long)(2 * s) * w4 + g) * bn + local] = v0;
-                        bplanes[((long)(2 * s + 1) * w4 + g) * bn + local] = v1;
-                    }
-                }
-            }
-            __syncthreads();
+            if (t >= ps && t < pe) pack_convert<W4>(sb, o0 - base, len, w4, s, tails, n, p0 + t, bplanes, bn, local);
             ps = pe;
         }
     }
-    if (t < np) lens[slot] = my_len[0] | (my_len[1] << 16);
 }
 
 // width class of every pair (granules of the longer string, minus one) and the class histogram
