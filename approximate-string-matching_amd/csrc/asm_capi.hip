@@ -762,9 +762,11 @@ int asm_accuracy_async(asm_handle* h, const int32_t* d_nw, const int32_t* d_leap
                        const int32_t* d_answers, int64_t n, unsigned long long* d_counters) {
     if (!h || !d_nw || !d_counters) return fail(h, ASM_EINVAL, "asm_accuracy_async: NULL argument");
     if (n <= 0) return ASM_OK;
+    if ((((uintptr_t)d_nw | (uintptr_t)d_leap | (uintptr_t)d_greedy | (uintptr_t)d_answers) & 15u) != 0)
+        return fail(h, ASM_EINVAL, "asm_accuracy_async: penalty arrays must be 16-byte aligned");
     HIPCHK(h, hipSetDevice(h->device));
-    int64_t blocks = (n + ASM_BLOCK - 1) / ASM_BLOCK;
-    if (blocks > 512) blocks = 512;
+    int64_t blocks = (n / 4 + ASM_BLOCK - 1) / ASM_BLOCK;
+    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
     hipLaunchKernelGGL(accuracy_kernel, dim3((unsigned)blocks), dim3(ASM_BLOCK), 0, h->stream, d_nw, d_leap, d_greedy,
                        d_answers, (long)n, d_counters);
     HIPCHK(h, hipGetLastError());

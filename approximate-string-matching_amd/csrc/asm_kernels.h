@@ -1082,13 +1082,37 @@ __global__ __launch_bounds__(ASM_BLOCK) void accuracy_kernel(const int32_t* __re
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
     unsigned int c_nw = 0, c_leap = 0, c_greedy = 0;
-    for (; i < n; i += stride) {
-        const int32_t p = nw[i];
+    // four pairs per thread and iteration: 16-byte loads, and enough independent loads in flight to cover HBM latency
+    const long n4 = n >> 2;
+    const int4* nw4 = reinterpret_cast<const int4*>(nw);
+    const int4* leap4 = reinterpret_cast<const int4*>(leap);
+    const int4* greedy4 = reinterpret_cast<const int4*>(greedy);
+    const int4* ans4 = reinterpret_cast<const int4*>(answers);
+    for (long q = i; q < n4; q += stride) {
+        const int4 p = nw4[q];
+        int4 want = p;
+        if (answers != nullptr) {
+            const int4 a = ans4[q];
+            want.x = a.x != INT32_MIN ? a.x : p.x, want.y = a.y != INT32_MIN ? a.y : p.y;
+            want.z = a.z != INT32_MIN ? a.z : p.z, want.w = a.w != INT32_MIN ? a.w : p.w;
+        }
+        c_nw += (p.x == want.x) + (p.y == want.y) + (p.z == want.z) + (p.w == want.w);
+        if (leap != nullptr) {
+            const int4 l = leap4[q];
+            c_leap += (l.x == want.x) + (l.y == want.y) + (l.z == want.z) + (l.w == want.w);
+        }
+        if (greedy != nullptr) {
+            const int4 g = greedy4[q];
+            c_greedy += (g.x == want.x) + (g.y == want.y) + (g.z == want.z) + (g.w == want.w);
+        }
+    }
+    for (long r = (n4 << 2) + i; r < n; r += stride) { /* the last n mod 4 pairs */
+        const int32_t p = nw[r];
         int32_t want = p;
-        if (answers != nullptr && answers[i] != INT32_MIN) want = answers[i];
+        if (answers != nullptr && answers[r] != INT32_MIN) want = answers[r];
         c_nw += (p == want) ? 1u : 0u;
-        if (leap != nullptr) c_leap += (leap[i] == want) ? 1u : 0u;
-        if (greedy != nullptr) c_greedy += (greedy[i] == want) ? 1u : 0u;
+        if (leap != nullptr) c_leap += (leap[r] == want) ? 1u : 0u;
+        if (greedy != nullptr) c_greedy += (greedy[r] == want) ? 1u : 0u;
     }
     const unsigned int t_nw = block_sum_256(c_nw, s_part);
     const unsigned int t_leap = block_sum_256(c_leap, s_part);

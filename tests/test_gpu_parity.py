@@ -209,3 +209,30 @@ def test_greedy_cigar(asm, engine, oracle, wl, n, k, mode):
     assert int(nops.max()) <= 64
     bad = [i for i in range(n) if cig[i] != want_cig[i]]
     assert not bad, (len(bad), bad[:3], cig[bad[0]], want_cig[bad[0]])
+
+
+def test_accuracy_counters(asm, engine, oracle):
+    """`_run_benchmark`'s counters (benchmark_utils.h:238,249-255) incl. an answers array; n not a multiple of 4."""
+    cfg, _, params = asm.workload("C2")
+    n = 9999
+    hb = asm.generate_pairs(cfg, 5, n)
+    batch = engine.upload(hb)
+    d = [engine.malloc(4 * n) for _ in range(3)]
+    d_cnt = engine.malloc(32)
+    engine.memset_async(d_cnt, 0, 32)
+    engine.run_benchmark_async(batch, params, d[0], d[1], d[2], d_cnt, repack=True)
+    nw, leap, greedy = oracle.nw(hb), oracle.leap(hb, 3), oracle.greedy(hb, 3, mode=1)
+    assert engine.to_host(d_cnt, 4, np.uint64).tolist() == [n, n, int((leap == nw).sum()), int((greedy == nw).sum())]
+    # answers file semantics (benchmark_utils.h:249-252,358-368): INT32_MIN means "use the NW penalty"
+    answers = nw.copy()
+    answers[::3] = np.iinfo(np.int32).min
+    answers[1::7] += 1
+    d_ans = engine.malloc(4 * n)
+    engine._chk(engine.lib.asm_memcpy_h2d(engine.h, d_ans, answers.ctypes.data, 4 * n))
+    engine.memset_async(d_cnt, 0, 32)
+    engine.accuracy_async(d[0], d[1], d[2], n, d_cnt, d_answers=d_ans)
+    want = np.where(answers == np.iinfo(np.int32).min, nw, answers)
+    assert engine.to_host(d_cnt, 4, np.uint64).tolist() == [n, int((nw == want).sum()), int((leap == want).sum()),
+                                                             int((greedy == want).sum())]
+    for p in d + [d_cnt, d_ans]:
+        engine.free(p)
