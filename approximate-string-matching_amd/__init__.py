@@ -122,6 +122,7 @@ def load_library() -> ctypes.CDLL:
         "asm_align_batch": (i32, [vp, i32, i64, vp, vp, vp, vp, c.POINTER(Params), i32, vp]),
         "asm_greedy_cigar_batch_async": (i32, [vp, vp, c.POINTER(Params), vp, vp, i32, vp]),
         "asm_cigar_format": (i32, [vp, i32, i32, vp, c.c_size_t]),
+        "asm_coverage": (i32, [vp, vp, c.POINTER(Params), vp, i32, vp, i32, vp, vp, i32, vp, vp]),
         "asm_count_equal_async": (i32, [vp, vp, vp, i64, vp]),
         "asm_accuracy_async": (i32, [vp, vp, vp, vp, vp, i64, vp]),
         "asm_run_benchmark_async": (i32, [vp, vp, c.POINTER(Params), i32, vp, vp, vp, vp, vp]),
@@ -364,13 +365,36 @@ class Engine:
         finally:
             for p in (d_pen, d_ops, d_nops):
                 self.free(p)
-        letters = np.array(list("MID?"))
-        cigars = []
-        for i in range(n):
-            k = min(int(nops[i]), cap)
-            row = ops[i, :k]
-            cigars.append("".join(f"{int(v) >> 2}{letters[int(v) & 3]}" for v in row))
-        return costs, cigars, nops
+        return costs, decode_cigars(ops, nops, cap), nops
+
+    def coverage(self, batch: DeviceBatch, params: Params, window: int = 64, cap: int = 64, want_nw_cigars: bool = False):
+        """The harness's coverage metric for every pair: -> dict(cover uint8[n] (1/0/2), covered, undetermined,
+        greedy_cost, greedy_cigars[, nw_cigars])."""
+        n = batch.n
+        d_pen, d_ops, d_nops = self.malloc(4 * max(n, 1)), self.malloc(2 * cap * max(n, 1)), self.malloc(max(n, 1))
+        d_cov, d_cnt = self.malloc(max(n, 1)), self.malloc(16)
+        d_nwo = self.malloc(2 * cap * max(n, 1)) if want_nw_cigars else None
+        d_nwn = self.malloc(max(n, 1)) if want_nw_cigars else None
+        try:
+            self._chk(self.lib.asm_greedy_cigar_batch_async(self.h, batch.ptr, ctypes.byref(params), d_pen, d_ops, cap,
+                                                            d_nops))
+            self.memset_async(d_cnt, 0, 16)
+            self._chk(self.lib.asm_coverage(self.h, batch.ptr, ctypes.byref(params), d_ops, cap, d_nops, window, d_cov,
+                                            d_nwo, cap, d_nwn, d_cnt))
+            cnt = self.to_host(d_cnt, 2, np.uint64)
+            out = {"cover": self.to_host(d_cov, n, np.uint8), "covered": int(cnt[0]), "undetermined": int(cnt[1]),
+                   "greedy_cost": self.to_host(d_pen, n)}
+            gops = self.to_host(d_ops, n * cap, np.uint16).reshape(n, cap)
+            out["greedy_cigars"] = decode_cigars(gops, self.to_host(d_nops, n, np.uint8), cap)
+            if want_nw_cigars:
+                nops = self.to_host(d_nwn, n, np.uint8)
+                out["nw_cigars"] = decode_cigars(self.to_host(d_nwo, n * cap, np.uint16).reshape(n, cap), nops, cap,
+                                                 reverse=True)
+            return out
+        finally:
+            for p in (d_pen, d_ops, d_nops, d_cov, d_cnt, d_nwo, d_nwn):
+                if p:
+                    self.free(p)
 
     def count_equal_async(self, d_a: int, d_b: int, n: int, d_count: int) -> None:
         self._chk(self.lib.asm_count_equal_async(self.h, d_a, d_b, n, d_count))
@@ -390,6 +414,18 @@ class Engine:
     # ---- timing ----
     def timer(self) -> "Timer":
         return Timer(self)
+
+
+def decode_cigars(ops: np.ndarray, nops: np.ndarray, cap: int, reverse: bool = False):
+    """Encoded rows (count << 3 | op; op 0 'M', 1 'I', 2 'D', 3 '=', 4 'X') -> CIGAR strings."""
+    letters = "MID=X???"
+    out = []
+    for i in range(ops.shape[0]):
+        row = ops[i, :min(int(nops[i]), cap)]
+        if reverse:
+            row = row[::-1]
+        out.append("".join(f"{int(v) >> 3}{letters[int(v) & 7]}" for v in row))
+    return out
 
 
 class Timer:

@@ -127,7 +127,7 @@ struct OutMap {
 };
 
 // Optional CIGAR output of the Greedy kernels (hurdle_matrix::_update_CIGAR, GASMA/hurdle_matrix.h:238-251): per pair
-// a row of `cap` uint16 entries (count << 2 | op, op 0 = 'M', 1 = 'I', 2 = 'D') and the number of entries produced
+// a row of `cap` uint16 entries (count << 3 | op, op 0 = 'M', 1 = 'I', 2 = 'D'; the NW traceback adds 3 = '=', 4 = 'X') and the number of entries produced
 // (which may exceed cap: the row is then truncated and the caller sees nops > cap).  ops == null disables it.
 struct CigarSink {
     uint16_t* ops;
@@ -135,7 +135,7 @@ struct CigarSink {
     int cap;
     ASM_DEV bool on() const { return ops != nullptr; }
     ASM_DEV void emit(long pair, int& cnt, int count, int op) const {
-        if (cnt < cap) ops[pair * cap + cnt] = (uint16_t)((count << 2) | op);
+        if (cnt < cap) ops[pair * cap + cnt] = (uint16_t)((count << 3) | op);
         cnt++;
     }
     // lane switch, then the run of (mis)matches — the two appends of _update_CIGAR

@@ -15,6 +15,7 @@
 #include "asm_kernels.h"
 #include "asm_wide.h"
 #include "asm_wave.h"
+#include "asm_cover.h"
 #include "asm_tails.h"
 
 struct asm_handle {
@@ -121,6 +122,42 @@ static hipError_t launch_leap_unit(asm_handle* h, const asm_bucket& b, OutMap ou
     if (b.maxlen <= 128) return launch_leap_unit_w<K, 2>(h, b, out);
     if (b.maxlen <= 256) return launch_leap_unit_w<K, 4>(h, b, out);
     return launch_leap_unit_w<K, 6>(h, b, out);
+}
+
+/* forward sweep + traceback/coverage for one width class with window W */
+template <int ND, int W>
+static int cover_bucket(asm_handle* h, const asm_bucket& b, const CoverArgs& ca) {
+    typedef typename TraceCell<W>::T Cell;
+    if (b.n == 0) return ASM_OK;
+    // scratch: [column][pair]; processed in slices of pairs so that it stays below ~6 GiB
+    const int64_t cols = b.maxlen > 0 ? b.maxlen : 1;
+    int64_t slice = (int64_t)(6ll << 30) / (cols * (int64_t)sizeof(Cell));
+    slice = slice > b.n ? b.n : (slice < 4096 ? 4096 : slice);
+    Cell* d_trace = nullptr;
+    int32_t* d_band = nullptr;
+    HIPCHK(h, hipMalloc((void**)&d_trace, (size_t)cols * (size_t)slice * sizeof(Cell)));
+    if (hipMalloc((void**)&d_band, sizeof(int32_t) * (size_t)slice) != hipSuccess) {
+        (void)hipFree(d_trace);
+        return fail(h, ASM_ENOMEM, "asm_coverage: hipMalloc failed");
+    }
+    int rc = ASM_OK;
+    for (int64_t lo = 0; lo < b.n && !rc; lo += slice) {
+        const int64_t cnt = b.n - lo < slice ? b.n - lo : slice;
+        // a slice is addressed as a sub-batch: plane rows keep the bucket's stride, so pass shifted base pointers
+        const uint4* planes = b.planes + lo;
+        const uint32_t* lens = b.lens + lo;
+        const uint32_t* order = b.order ? b.order + lo : nullptr;
+        // the kernels index planes as [(p*w4+g)*n + i] with n = pairs of the BUCKET: use dedicated strided variants
+        hipLaunchKernelGGL((nw_trace_forward_kernel<ND, W>), dim3(grid_for(cnt)), dim3(ASM_BLOCK), 0, h->stream, planes, lens,
+                           (long)cnt, (long)b.n, b.w4, d_trace, d_band);
+        hipLaunchKernelGGL((nw_trace_cover_kernel<ND / 2, W>), dim3(grid_for(cnt)), dim3(ASM_BLOCK), 0, h->stream, planes, lens,
+                           (long)cnt, (long)b.n, b.w4, (const Cell*)d_trace, (const int32_t*)d_band, order, lo, ca);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
+            rc = fail(h, ASM_ENODEVICE, "asm_coverage: kernel failed");
+    }
+    (void)hipFree(d_trace);
+    (void)hipFree(d_band);
+    return rc;
 }
 
 extern "C" {
@@ -717,12 +754,41 @@ int asm_cigar_format(const uint16_t* ops, int nops, int cap, char* out, size_t o
     out[0] = 0;
     const int cnt = nops < cap ? nops : cap;
     for (int i = 0; i < cnt; i++) {
-        const char op = "MID?"[ops[i] & 3];
-        const int w = snprintf(out + len, out_cap - len, "%d%c", (int)(ops[i] >> 2), op);
+        const char op = "MID=X???"[ops[i] & 7];
+        const int w = snprintf(out + len, out_cap - len, "%d%c", (int)(ops[i] >> 3), op);
         if (w < 0 || len + (size_t)w >= out_cap) return ASM_EINVAL;
         len += (size_t)w;
     }
     return nops > cap ? ASM_EUNSUPPORTED : ASM_OK; /* truncated row */
+}
+
+int asm_coverage(asm_handle* h, const asm_batch* b, const asm_params* p, const uint16_t* d_greedy_ops, int greedy_cap,
+                 const uint8_t* d_greedy_nops, int window, uint8_t* d_cover, uint16_t* d_nw_ops, int nw_cap,
+                 uint8_t* d_nw_nops, unsigned long long* d_counters) {
+    if (!h || !b || !p || !d_greedy_ops || !d_greedy_nops || !d_cover || !d_counters || greedy_cap < 1)
+        return fail(h, ASM_EINVAL, "asm_coverage: bad argument");
+    if (p->x != 1 || p->o != 1 || p->e != 1)
+        return fail(h, ASM_EUNSUPPORTED, "asm_coverage: the NW traceback is built for unit penalties (x = o = e = 1) only");
+    if (window != 32 && window != 64) return fail(h, ASM_EINVAL, "asm_coverage: window must be 32 or 64");
+    if (d_nw_ops && (!d_nw_nops || nw_cap < 1)) return fail(h, ASM_EINVAL, "asm_coverage: bad NW CIGAR buffers");
+    if (b->n == 0) return ASM_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    CoverArgs ca;
+    ca.g_ops = d_greedy_ops, ca.g_nops = d_greedy_nops, ca.g_cap = greedy_cap;
+    ca.cover = d_cover, ca.nw_ops = d_nw_ops, ca.nw_nops = d_nw_nops, ca.nw_cap = nw_cap, ca.counters = d_counters;
+    int rc = ASM_OK;
+    for (int q = 0; q < b->nb && !rc; q++) {
+        const asm_bucket& k = b->bk[q];
+#define COVER(ND) rc = window == 32 ? cover_bucket<ND, 32>(h, k, ca) : cover_bucket<ND, 64>(h, k, ca)
+        switch (k.w4) {
+            case 1: COVER(4); break;
+            case 2: COVER(8); break;
+            case 3: COVER(12); break;
+            default: COVER(16); break;
+        }
+#undef COVER
+    }
+    return rc;
 }
 
 int asm_align_batch(asm_handle* h, int aligner, int64_t n, const char* reads, const uint32_t* read_off, const char* refs,

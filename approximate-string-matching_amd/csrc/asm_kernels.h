@@ -941,9 +941,16 @@ struct BandWord<64> {
     typedef u64 T;
 };
 
-template <int ND, int W> /* ND = plane dwords per string (4 * w4); A arrays carry two zero dwords of padding */
+struct NoColumnSink {
+    template <typename WT>
+    ASM_DEV void operator()(int, WT, WT) const {}
+};
+
+// `sink(j, VP, VN)` sees the vertical delta vectors of every finished column j (1-based, in that column's window
+// coordinates); the traceback of asm_cover.h stores them.
+template <int ND, int W, typename Sink = NoColumnSink> /* ND = plane dwords per string (4 * w4); A arrays carry two zero dwords of padding */
 ASM_DEV int nw_band(const uint32_t (&A0)[ND + 2], const uint32_t (&A1)[ND + 2], const uint32_t (&B0)[ND],
-                    const uint32_t (&B1)[ND], int m, int nn) {
+                    const uint32_t (&B1)[ND], int m, int nn, const Sink& sink = Sink()) {
     typedef typename BandWord<W>::T WT;
     constexpr int C = W / 2;          /* window top row of column j is max(1, j - C + 1) */
     constexpr int NBLK = ND * 32 / W; /* W-column blocks */
@@ -979,7 +986,10 @@ ASM_DEV int nw_band(const uint32_t (&A0)[ND + 2], const uint32_t (&A1)[ND + 2], 
     {
         const WT b0 = BLK(B0, 0), b1 = BLK(B1, 0);
         const int c1 = nn < C ? nn : C;
-        for (int r = 0; r < c1; r++) NW_BAND_COLUMN(false, b0, b1, r)
+        for (int r = 0; r < c1; r++) {
+            NW_BAND_COLUMN(false, b0, b1, r)
+            sink(r + 1, VP, VN);
+        }
     }
     // columns C+1..n: slide one row per column; the reservoir's upper word is refilled every W slides
 #pragma unroll
@@ -991,6 +1001,7 @@ ASM_DEV int nw_band(const uint32_t (&A0)[ND + 2], const uint32_t (&A1)[ND + 2], 
         for (int r = r0; r < rend; r++) {
             if (r == C) hi0 = BLK(A0, bq + 1), hi1 = BLK(A1, bq + 1); /* wave-uniform */
             NW_BAND_COLUMN(true, b0, b1, r)
+            sink(W * bq + r + 1, VP, VN);
         }
     }
 #undef NW_BAND_COLUMN

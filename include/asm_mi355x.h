@@ -119,12 +119,22 @@ int asm_align_batch_async(asm_handle* h, const asm_batch* b, int aligner, const 
                           int32_t* d_penalties);
 /* Greedy with its CIGAR (hurdle_matrix::get_CIGAR, hurdle_matrix.h:613; built by _update_CIGAR :238-251 — lane switches
  * as nI / nD, runs of matches AND mismatches as nM, and the final hop's run is the hurdle count, :589).  d_ops = device
- * uint16[n][cap], entry = count << 2 | op with op 0 'M', 1 'I', 2 'D'; d_nops = device uint8[n] = entries produced (a
+ * uint16[n][cap], entry = count << 3 | op with op 0 'M', 1 'I', 2 'D' (3 '=' and 4 'X' appear in NW CIGARs only); d_nops = device uint8[n] = entries produced (a
  * value above cap means the row was truncated).  Enqueue only. */
 int asm_greedy_cigar_batch_async(asm_handle* h, const asm_batch* b, const asm_params* p, int32_t* d_penalties,
                                  uint16_t* d_ops, int cap, uint8_t* d_nops);
 /* Host helper: formats one encoded row as the reference's string ("22M1D50M1D28M"). */
 int asm_cigar_format(const uint16_t* ops, int nops, int cap, char* out, size_t out_cap);
+/* The harness's coverage counter (benchmark_utils.h:214-225,256-258; benchmark_coverage.h:26-91): for every pair,
+ * does LCM(read, Greedy CIGAR, threshold 1) cover LCM(read, NW CIGAR, threshold 3)?  Needs the Greedy CIGAR rows of
+ * asm_greedy_cigar_batch_async.  The NW alignment is traced back on the device with this library's own documented
+ * preference (diagonal, then gap in the read, then gap in the reference — parasail's is internal and unpinned); unit
+ * penalties only.  `window` = 32 or 64 rows of banded DP: pairs whose distance is above window/2 - 3 get flag 2.
+ * d_cover[i] = 1 covers / 0 does not / 2 not determined; d_counters[0] += covered, d_counters[1] += not determined.
+ * d_nw_ops (optional) receives the NW CIGAR rows in traceback (reverse) order, entries as above.  Synchronous. */
+int asm_coverage(asm_handle* h, const asm_batch* b, const asm_params* p, const uint16_t* d_greedy_ops, int greedy_cap,
+                 const uint8_t* d_greedy_nops, int window, uint8_t* d_cover, uint16_t* d_nw_ops, int nw_cap,
+                 uint8_t* d_nw_nops, unsigned long long* d_counters);
 /* Convenience: host in, host out (upload + pack + align + copy back).  The reference-shaped call:
  * align(read, ref, k) for every pair of the batch. */
 int asm_align_batch(asm_handle* h, int aligner, int64_t n, const char* reads, const uint32_t* read_off,
