@@ -132,6 +132,8 @@ class benchmark {
     std::vector<uint32_t> ro_{0}, fo_{0};
     std::vector<int32_t> answers_;
     unsigned long long counters_[4] = {0, 0, 0, 0};
+    unsigned long long cover_[2] = {0, 0}; /* covered, not determined */
+    bool have_cover_ = false;
     float ms_[3] = {0, 0, 0};
     std::vector<int32_t> pen_[3];
 
@@ -194,6 +196,22 @@ public:
         check(h, asm_accuracy_async(h, (int32_t*)d_pen[0], (int32_t*)d_pen[1], (int32_t*)d_pen[2], (int32_t*)d_ans, n,
                                     (unsigned long long*)d_cnt));
         check(h, asm_memcpy_d2h(h, counters_, d_cnt, 32));
+        // [Coverage] (benchmark_utils.h:256-258): Greedy CIGAR + NW traceback on the device; unit penalties only
+        if (p_.x == 1 && p_.o == 1 && p_.e == 1 && n > 0) {
+            const int cap = 96;
+            void *d_ops = nullptr, *d_nops = nullptr, *d_cov = nullptr, *d_cc = nullptr;
+            check(h, asm_device_malloc(h, sizeof(uint16_t) * (size_t)cap * (size_t)n, &d_ops));
+            check(h, asm_device_malloc(h, (size_t)n, &d_nops));
+            check(h, asm_device_malloc(h, (size_t)n, &d_cov));
+            check(h, asm_device_malloc(h, 16, &d_cc));
+            check(h, asm_memset_async(h, d_cc, 0, 16));
+            check(h, asm_greedy_cigar_batch_async(h, b, &p_, (int32_t*)d_pen[2], (uint16_t*)d_ops, cap, (uint8_t*)d_nops));
+            check(h, asm_coverage(h, b, &p_, (uint16_t*)d_ops, cap, (uint8_t*)d_nops, 64, (uint8_t*)d_cov, nullptr, 0, nullptr,
+                                  (unsigned long long*)d_cc));
+            check(h, asm_memcpy_d2h(h, cover_, d_cc, 16));
+            have_cover_ = true;
+            asm_device_free(h, d_ops), asm_device_free(h, d_nops), asm_device_free(h, d_cov), asm_device_free(h, d_cc);
+        }
         for (int a = 0; a < 3; a++) {
             pen_[a].resize((size_t)n);
             if (n) check(h, asm_memcpy_d2h(h, pen_[a].data(), d_pen[a], sizeof(int32_t) * (size_t)n));
@@ -219,7 +237,15 @@ public:
         printf("=> LEAP             | %.3f %%\n", (double)counters_[2] / total * 100);
         printf("=> Greedy           | %.3f %%\n", (double)counters_[3] / total * 100);
         printf("[Coverage] (percentage of alignments covering all long consecutive matches)\n");
-        printf("=> Greedy           | not computed (CIGAR/coverage row is not on the device path yet)\n");
+        if (have_cover_) {
+            printf("=> Greedy           | %.3f %%\n", (double)cover_[0] / (total - (double)cover_[1]) * 100);
+            if (cover_[1])
+                printf("   (%llu pairs beyond the traceback band are excluded; NW tie-break is this library's, not parasail's)\n",
+                       cover_[1]);
+        } else {
+            printf("=> Greedy           | not computed (the device NW traceback covers x = o = e = 1 only)\n");
+        }
+        printf("[GPU kernel time] NW %.3f ms | LEAP %.3f ms | Greedy %.3f ms\n", ms_[0], ms_[1], ms_[2]);
     }
 };
 

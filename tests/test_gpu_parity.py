@@ -193,6 +193,11 @@ def test_asm_bench_harness_prints_reference_block(asm, oracle, tmp_path):
         acc = lines[lines.index("[Accuracy] (percentage of alignments matching optimal penalty)") + 1:][:3]
         for line, (name, val) in zip(acc, want.items()):
             assert line == "=> %-16s | %.3f %%" % (name, val), (line, name, val)
+        # [Coverage]: Greedy CIGAR vs the NW traceback (this library's documented tie-break = the oracle's)
+        gc = oracle.greedy(hb, 3, mode=mode, cigars=True)[1]
+        cov = oracle.coverage(hb, gc, 1, oracle.nw_cigar(hb)[1], 3)
+        i = lines.index("[Coverage] (percentage of alignments covering all long consecutive matches)")
+        assert lines[i + 1] == "=> %-16s | %.3f %%" % ("Greedy", 100.0 * float(cov.mean())), lines[i + 1]
 
 
 @pytest.mark.parametrize("wl,n,k,mode", [("C2", 20000, 3, 1), ("C2", 8000, 3, 0), ("C1", 5000, 2, 1), ("C3", 3000, 30, 1),
