@@ -119,6 +119,7 @@ def load_library() -> ctypes.CDLL:
         "asm_batch_download": (i32, [vp, vp, vp, vp, vp, c.c_size_t, vp, c.c_size_t]),
         "asm_batch_pack_async": (i32, [vp, vp]),
         "asm_align_batch_async": (i32, [vp, vp, i32, c.POINTER(Params), vp]),
+        "asm_align_batch_hinted_async": (i32, [vp, vp, i32, c.POINTER(Params), vp, vp]),
         "asm_align_batch": (i32, [vp, i32, i64, vp, vp, vp, vp, c.POINTER(Params), i32, vp]),
         "asm_greedy_cigar_batch_async": (i32, [vp, vp, c.POINTER(Params), vp, vp, i32, vp]),
         "asm_cigar_format": (i32, [vp, i32, i32, vp, c.c_size_t]),
@@ -332,6 +333,10 @@ class Engine:
     def align_async(self, batch: DeviceBatch, aligner: int, params: Params, d_out: int) -> None:
         """One aligner over a resident batch into a device int32[n] buffer (enqueue only)."""
         self._chk(self.lib.asm_align_batch_async(self.h, batch.ptr, aligner, ctypes.byref(params), d_out))
+
+    def align_hinted_async(self, batch: DeviceBatch, aligner: int, params: Params, d_hint: Optional[int], d_out: int) -> None:
+        """align_async with a per-pair work estimate (device int32[n]) that only steers scheduling."""
+        self._chk(self.lib.asm_align_batch_hinted_async(self.h, batch.ptr, aligner, ctypes.byref(params), d_hint, d_out))
 
     def align(self, batch: DeviceBatch, aligner: int, params: Params) -> np.ndarray:
         d_out = self.malloc(4 * max(batch.n, 1))

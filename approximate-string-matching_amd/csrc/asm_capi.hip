@@ -27,6 +27,7 @@ struct asm_handle {
     bool persist = true;                  /* Greedy: lane-refilling persistent kernel (ASM_PERSIST=0 disables) */
     bool persist_leap = false;            /* LEAP: the plain one-pair-per-thread kernel is faster at 1e6 pairs (ASM_PERSIST_LEAP=1) */
     int refill_greedy = 8, refill_leap = 16; /* lanes that must be idle before a wave refills (tunable by env) */
+    bool leap_hint = true;                /* LEAP scheduled by a work hint when one is given (ASM_LEAP_HINT=0 disables) */
     bool bucketing = true;                /* group mixed-length batches by width class (ASM_BUCKET=0 disables) */
     bool wave_kernels = true;             /* wave-per-pair kernels for 6 <= k <= 31 (ASM_WAVE=0: workgroup-per-pair LDS kernels) */
     bool nw_banded = true;                /* banded bit-parallel NW with in-kernel full-height recompute (ASM_NW_BANDED=0) */
@@ -108,7 +109,13 @@ static hipError_t launch_greedy(asm_handle* h, const asm_bucket& b, const Greedy
 }
 
 template <int K, int W64>
-static hipError_t launch_leap_unit_w(asm_handle* h, const asm_bucket& b, OutMap out) {
+static hipError_t launch_leap_unit_w(asm_handle* h, const asm_bucket& b, OutMap out, const int32_t* hint) {
+    if (hint && h->leap_hint) {
+        const unsigned blocks = (unsigned)((b.n + LEAP_HINT_PAIRS - 1) / LEAP_HINT_PAIRS);
+        hipLaunchKernelGGL((leap_unit_hint_kernel<K, W64>), dim3(blocks), dim3(ASM_BLOCK), 0, h->stream, b.planes, b.lens,
+                           (long)b.n, b.w4, out, hint);
+        return hipGetLastError();
+    }
     if (h->persist_leap)
         return launch_persistent(h, leap_unit_persist_kernel<K, W64>, b.n, (const uint4*)b.planes, (const uint32_t*)b.lens,
                                  (long)b.n, b.w4, out, h->refill_leap);
@@ -118,10 +125,10 @@ static hipError_t launch_leap_unit_w(asm_handle* h, const asm_bucket& b, OutMap 
 }
 
 template <int K>
-static hipError_t launch_leap_unit(asm_handle* h, const asm_bucket& b, OutMap out) {
-    if (b.maxlen <= 128) return launch_leap_unit_w<K, 2>(h, b, out);
-    if (b.maxlen <= 256) return launch_leap_unit_w<K, 4>(h, b, out);
-    return launch_leap_unit_w<K, 6>(h, b, out);
+static hipError_t launch_leap_unit(asm_handle* h, const asm_bucket& b, OutMap out, const int32_t* hint) {
+    if (b.maxlen <= 128) return launch_leap_unit_w<K, 2>(h, b, out, hint);
+    if (b.maxlen <= 256) return launch_leap_unit_w<K, 4>(h, b, out, hint);
+    return launch_leap_unit_w<K, 6>(h, b, out, hint);
 }
 
 /* forward sweep + traceback/coverage for one width class with window W */
@@ -198,6 +205,7 @@ int asm_create(asm_handle** out, int device) {
     const char* env = getenv("ASM_PERSIST");
     h->persist = !(env && env[0] == '0');
     if ((env = getenv("ASM_PERSIST_LEAP"))) h->persist_leap = env[0] != '0';
+    if ((env = getenv("ASM_LEAP_HINT"))) h->leap_hint = env[0] != '0';
     if ((env = getenv("ASM_BUCKET"))) h->bucketing = env[0] != '0';
     if ((env = getenv("ASM_WAVE"))) h->wave_kernels = env[0] != '0';
     if ((env = getenv("ASM_NW_BANDED"))) h->nw_banded = env[0] != '0';
@@ -640,7 +648,7 @@ static int check_params(asm_handle* h, int aligner, const asm_params* p) {
 
 /* one aligner over one width class */
 static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const asm_params* p, OutMap out,
-                        CigarSink cig = CigarSink{nullptr, nullptr, 0}) {
+                        CigarSink cig = CigarSink{nullptr, nullptr, 0}, const int32_t* hint = nullptr) {
     if (b.n == 0) return ASM_OK;
     const bool unit = (p->x == 1 && p->o == 1 && p->e == 1);
     const uint4* planes = b.planes;
@@ -668,11 +676,11 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
     } else if (aligner == ASM_LEAP) {
         if (unit && p->k >= 1 && p->k <= 5 && b.maxlen <= 384) {
             switch (p->k) {
-                case 1: HIPCHK(h, launch_leap_unit<1>(h, b, out)); break;
-                case 2: HIPCHK(h, launch_leap_unit<2>(h, b, out)); break;
-                case 3: HIPCHK(h, launch_leap_unit<3>(h, b, out)); break;
-                case 4: HIPCHK(h, launch_leap_unit<4>(h, b, out)); break;
-                default: HIPCHK(h, launch_leap_unit<5>(h, b, out)); break;
+                case 1: HIPCHK(h, launch_leap_unit<1>(h, b, out, hint)); break;
+                case 2: HIPCHK(h, launch_leap_unit<2>(h, b, out, hint)); break;
+                case 3: HIPCHK(h, launch_leap_unit<3>(h, b, out, hint)); break;
+                case 4: HIPCHK(h, launch_leap_unit<4>(h, b, out, hint)); break;
+                default: HIPCHK(h, launch_leap_unit<5>(h, b, out, hint)); break;
             }
         } else if (unit && p->k <= ASM_WAVE_MAX_K && h->wave_kernels) {
 #define LEAP_WAVE(W) \
@@ -714,6 +722,22 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
     }
     HIPCHK(h, hipGetLastError());
     return ASM_OK;
+}
+
+int asm_align_batch_hinted_async(asm_handle* h, const asm_batch* b, int aligner, const asm_params* p,
+                                 const int32_t* d_work_hint, int32_t* d_penalties) {
+    if (!h || !b || !d_penalties) return fail(h, ASM_EINVAL, "asm_align_batch_hinted_async: NULL argument");
+    int rc = check_params(h, aligner, p);
+    if (rc) return rc;
+    if (b->n == 0) return ASM_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    for (int q = 0; q < b->nb && !rc; q++) {
+        OutMap out;
+        out.out = d_penalties;
+        out.order = b->bk[q].order;
+        rc = align_bucket(h, b->bk[q], aligner, p, out, CigarSink{nullptr, nullptr, 0}, d_work_hint);
+    }
+    return rc;
 }
 
 int asm_align_batch_async(asm_handle* h, const asm_batch* b, int aligner, const asm_params* p, int32_t* d_penalties) {
@@ -846,7 +870,8 @@ int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, in
     int rc = ASM_OK;
     if (repack) rc = asm_batch_pack_async(h, b);
     if (!rc && d_nw) rc = asm_align_batch_async(h, b, ASM_NW, p, d_nw);
-    if (!rc && d_leap) rc = asm_align_batch_async(h, b, ASM_LEAP, p, d_leap);
+    /* LEAP is scheduled by the NW penalties just computed (same work, sorted inside each workgroup) */
+    if (!rc && d_leap) rc = asm_align_batch_hinted_async(h, b, ASM_LEAP, p, d_nw, d_leap);
     if (!rc && d_greedy) rc = asm_align_batch_async(h, b, ASM_GREEDY, p, d_greedy);
     if (!rc && d_counters && d_nw) rc = asm_accuracy_async(h, d_nw, d_leap, d_greedy, d_answers, b->n, d_counters);
     return rc;

@@ -669,12 +669,8 @@ ASM_DEV VW<W64> leap_lane_mask(const VW<W64>& A0, const VW<W64>& A1, const VW<W6
 }
 
 template <int K, int W64>
-__global__ __launch_bounds__(ASM_BLOCK) void leap_unit_kernel(const uint4* __restrict__ planes,
-                                                              const uint32_t* __restrict__ lens, long n, int w4,
-                                                              OutMap out) {
+ASM_DEV int leap_unit_pair(const uint4* __restrict__ planes, const uint32_t* __restrict__ lens, long n, int w4, long i) {
     constexpr int NL = 2 * K + 1;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
     const uint32_t ln = lens[i];
     const int m = (int)(ln & 0xffffu), nn = (int)(ln >> 16);
     const int len = m > nn ? m : nn; /* benchmark_utils.h:162 */
@@ -738,7 +734,73 @@ __global__ __launch_bounds__(ASM_BLOCK) void leap_unit_kernel(const uint4* __res
         for (int j = 0; j < NL; j++) en[j] = en2[j], ip[j] = ip2[j], dp[j] = dp2[j];
         if (pass) result = e; /* final_ED (LV_BAG.cpp:228,356-358), not converge_ED */
     }
-    out.put(i, result);
+    return result;
+}
+
+template <int K, int W64>
+__global__ __launch_bounds__(ASM_BLOCK) void leap_unit_kernel(const uint4* __restrict__ planes,
+                                                              const uint32_t* __restrict__ lens, long n, int w4,
+                                                              OutMap out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out.put(i, leap_unit_pair<K, W64>(planes, lens, n, w4, i));
+}
+
+// Work-sorted form.  A pair needs final_ED + 1 generations, and a wave runs as long as its slowest pair: with pairs in
+// input order a wave of 64 runs ~16 generations for a mean of ~8.  When a per-pair work estimate is at hand — the NW
+// penalty of the same pair, computed one kernel earlier in `_run_benchmark`, is within one generation of LEAP's count
+// for ~98 % of pairs — each workgroup counting-sorts its 256 pairs by that hint in LDS and thread t takes the pair of
+// rank t, so each of the four waves works on one quartile of the workgroup's pairs, i.e. on 64 pairs that need
+// (nearly) the same number of generations.  The hint only changes the schedule, never a result.
+#define LEAP_HINT_PAIRS 256
+template <int K, int W64>
+__global__ __launch_bounds__(ASM_BLOCK) void leap_unit_hint_kernel(const uint4* __restrict__ planes,
+                                                                   const uint32_t* __restrict__ lens, long n, int w4,
+                                                                   OutMap out, const int32_t* __restrict__ hint) {
+    __shared__ uint16_t s_sorted[LEAP_HINT_PAIRS];
+    __shared__ int s_bin[64];
+    const int t = threadIdx.x;
+    const long base = (long)blockIdx.x * LEAP_HINT_PAIRS;
+    const int cnt = (n - base) < LEAP_HINT_PAIRS ? (int)(n - base) : LEAP_HINT_PAIRS;
+    if (t < 64) s_bin[t] = 0;
+    __syncthreads();
+    int key[LEAP_HINT_PAIRS / ASM_BLOCK];
+#pragma unroll
+    for (int q = 0; q < LEAP_HINT_PAIRS / ASM_BLOCK; q++) {
+        const int local = t + q * ASM_BLOCK;
+        key[q] = -1;
+        if (local < cnt) {
+            int h = hint[out.index(base + local)];
+            h = h < 0 ? 63 : (h > 63 ? 63 : h);
+            key[q] = h;
+            atomicAdd(&s_bin[h], 1);
+        }
+    }
+    __syncthreads();
+    if (t == 0) { /* exclusive scan of 64 bins */
+        int run = 0;
+        for (int b = 0; b < 64; b++) {
+            const int c = s_bin[b];
+            s_bin[b] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < LEAP_HINT_PAIRS / ASM_BLOCK; q++) {
+        if (key[q] >= 0) {
+            const int slot = atomicAdd(&s_bin[key[q]], 1);
+            s_sorted[slot] = (uint16_t)(t + q * ASM_BLOCK);
+        }
+    }
+    __syncthreads();
+    for (int q = 0; q < LEAP_HINT_PAIRS / ASM_BLOCK; q++) {
+        const int p = t + q * ASM_BLOCK;
+        if (p < cnt) {
+            const long i = base + s_sorted[p];
+            out.put(i, leap_unit_pair<K, W64>(planes, lens, n, w4, i));
+        }
+    }
 }
 
 // Persistent, lane-refilling form of leap_unit_kernel<K,W64>: a pair needs final_ED+1 generations (mean ~8, max >30

@@ -100,7 +100,8 @@ def main():
             return
         seq = [("pack", lambda: eng.pack_async(batch))]
         for a in aligners:
-            seq.append((asm.ALIGNER_NAMES[a], lambda a=a: eng.align_async(batch, a, params, d_pen[a])))
+            hint = d_nw if a == asm.LEAP else None  # as asm_run_benchmark_async does: LEAP scheduled by the NW penalties
+            seq.append((asm.ALIGNER_NAMES[a], lambda a=a, hint=hint: eng.align_hinted_async(batch, a, params, hint, d_pen[a])))
         for name, fn in seq:
             t = eng.timer()
             t.start()

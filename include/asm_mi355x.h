@@ -117,6 +117,11 @@ int asm_batch_pack_async(asm_handle* h, asm_batch* b);
  * (hurdle_matrix.h:677). */
 int asm_align_batch_async(asm_handle* h, const asm_batch* b, int aligner, const asm_params* p,
                           int32_t* d_penalties);
+/* Same as asm_align_batch_async with an optional per-pair work estimate (device int32[n], input order; NULL = none).
+ * The estimate only steers scheduling — LEAP sorts each workgroup's pairs by it so that a wave's 64 pairs need about the
+ * same number of generations — and never changes a result.  `_run_benchmark` passes the NW penalties of the same pairs. */
+int asm_align_batch_hinted_async(asm_handle* h, const asm_batch* b, int aligner, const asm_params* p,
+                                 const int32_t* d_work_hint, int32_t* d_penalties);
 /* Greedy with its CIGAR (hurdle_matrix::get_CIGAR, hurdle_matrix.h:613; built by _update_CIGAR :238-251 — lane switches
  * as nI / nD, runs of matches AND mismatches as nM, and the final hop's run is the hurdle count, :589).  d_ops = device
  * uint16[n][cap], entry = count << 3 | op with op 0 'M', 1 'I', 2 'D' (3 '=' and 4 'X' appear in NW CIGARs only); d_nops = device uint8[n] = entries produced (a

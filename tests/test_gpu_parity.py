@@ -266,3 +266,21 @@ def test_coverage_counter_and_nw_traceback(asm, engine, oracle, wl, n, window):
     assert not wrong, (len(wrong), got["nw_cigars"][wrong[0]], ncig[wrong[0]])
     if wl == "C2":
         assert det.all() and 0.90 < want.mean() < 0.99  # README.md:36 reports 94.2 % with parasail's traceback
+
+
+def test_leap_work_hint_changes_schedule_not_results(asm, engine, oracle):
+    """LEAP scheduled by a per-pair work estimate (the NW penalties; also garbage and mixed-length batches)."""
+    for wl, n in (("C2", 30000), ("C5", 9000)):
+        cfg, _, params = asm.workload(wl)
+        hb = asm.generate_pairs(cfg, 2, n)
+        batch = engine.upload(hb)
+        want = oracle.leap(hb, k=3)
+        d_nw, d_leap = engine.malloc(4 * n), engine.malloc(4 * n)
+        engine.align_async(batch, asm.NW, params, d_nw)
+        engine.align_hinted_async(batch, asm.LEAP, params, d_nw, d_leap)
+        _check("hinted by NW", engine.to_host(d_leap, n), want, hb)
+        junk = (np.arange(n, dtype=np.int32) * 7919) % 200 - 50
+        engine._chk(engine.lib.asm_memcpy_h2d(engine.h, d_nw, junk.ctypes.data, 4 * n))
+        engine.align_hinted_async(batch, asm.LEAP, params, d_nw, d_leap)
+        _check("hinted by junk", engine.to_host(d_leap, n), want, hb)
+        engine.free(d_nw), engine.free(d_leap)

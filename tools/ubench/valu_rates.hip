@@ -1,85 +1,102 @@
-// Micro-benchmark: issue cost of the integer/bit instructions the aligner kernels are made of (gfx950).
-// Each kernel runs 8 independent chains of one operation so the result is throughput, not latency.
+// Micro-benchmark: issue cost (cycles per wave-instruction per SIMD) of the integer/bit instructions the aligner
+// kernels are made of, on gfx950.  Each kernel is a loop of 16 independent single-instruction chains written in inline
+// asm, so the number is throughput of exactly that instruction with 8 waves resident per SIMD.
 // build: hipcc -O3 --offload-arch=gfx950 -o valu_rates valu_rates.hip ; run on the GPU box.
 #include <hip/hip_runtime.h>
-#include <cstdio>
 #include <cstdint>
-typedef unsigned long long u64;
-#define ITER 4096
-#define CHAINS 8
+#include <cstdio>
+#define ITER 2048
+#define CH 16
 
-#define KERNEL(name, T, INIT, OP)                                                        \
-    __global__ __launch_bounds__(256) void name(T* out, int s, T seed) {                 \
-        T v[CHAINS];                                                                     \
-        for (int c = 0; c < CHAINS; c++) v[c] = INIT;                                    \
-        for (int it = 0; it < ITER; it++) {                                              \
-            _Pragma("unroll") for (int c = 0; c < CHAINS; c++) { OP; }                   \
-        }                                                                                \
-        T acc = 0;                                                                       \
-        for (int c = 0; c < CHAINS; c++) acc += v[c];                                    \
-        out[blockIdx.x * blockDim.x + threadIdx.x] = acc;                                \
+#define BENCH32(name, ASM)                                                                  \
+    __global__ __launch_bounds__(256) void name(uint32_t* out, uint32_t a, uint32_t b) {    \
+        uint32_t v[CH];                                                                     \
+        for (int c = 0; c < CH; c++) v[c] = a + threadIdx.x * 3 + c;                        \
+        uint32_t w = b + threadIdx.x;                                                       \
+        for (int it = 0; it < ITER; it++) {                                                 \
+            _Pragma("unroll") for (int c = 0; c < CH; c++) asm volatile(ASM : "+v"(v[c]) : "v"(w), "s"(b)); \
+        }                                                                                   \
+        uint32_t acc = 0;                                                                   \
+        for (int c = 0; c < CH; c++) acc ^= v[c];                                           \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = acc;                                   \
     }
 
-KERNEL(k_add32, uint32_t, seed + threadIdx.x + c, v[c] = v[c] + (uint32_t)s)
-KERNEL(k_xor32, uint32_t, seed + threadIdx.x + c, v[c] = (v[c] ^ (uint32_t)s) + 1u)
-KERNEL(k_shl32, uint32_t, seed + threadIdx.x + c, v[c] = (v[c] << (s & 31)) + 1u)
-KERNEL(k_shl64, u64, seed + threadIdx.x + c, v[c] = (v[c] << (s & 63)) + 1ull)
-KERNEL(k_shr64v, u64, seed + threadIdx.x + c, v[c] = (v[c] >> (v[c] & 7)) + 0x100000001ull)
-KERNEL(k_add64, u64, seed + threadIdx.x + c, v[c] = v[c] + (u64)s * 0x100000001ull)
-KERNEL(k_ctz32, uint32_t, seed + threadIdx.x + c, v[c] = (uint32_t)__builtin_ctz(v[c] | 0x80000000u) + v[c])
-KERNEL(k_ctz64, u64, seed + threadIdx.x + c, v[c] = (u64)__builtin_ctzll(v[c] | (1ull << 63)) + v[c])
-KERNEL(k_pop32, uint32_t, seed + threadIdx.x + c, v[c] = (uint32_t)__popc(v[c]) + v[c])
-KERNEL(k_pop64, u64, seed + threadIdx.x + c, v[c] = (u64)__popcll(v[c]) + v[c])
-KERNEL(k_mul32, uint32_t, seed + threadIdx.x + c, v[c] = v[c] * 0x00204081u + 1u)
-KERNEL(k_alignbit, uint32_t, seed + threadIdx.x + c, v[c] = __builtin_amdgcn_alignbit(v[c], (uint32_t)seed, (uint32_t)s) + 1u)
-KERNEL(k_cndmask, uint32_t, seed + threadIdx.x + c, v[c] = (v[c] > (uint32_t)s ? v[c] - 3u : v[c] + 7u))
-KERNEL(k_min32, uint32_t, seed + threadIdx.x + c, v[c] = min(v[c] + 5u, (uint32_t)s * 977u + c))
-KERNEL(k_fma64, double, (double)(seed + threadIdx.x + c), v[c] = __fma_rn(v[c], 1.0000001, (double)s))
-KERNEL(k_cvt64, double, (double)(seed + threadIdx.x + c), v[c] = (double)((int)v[c] + s))
-KERNEL(k_bfe, uint32_t, seed + threadIdx.x + c, v[c] = ((v[c] >> (s & 31)) & 1u) + v[c] + 1u)
+#define BENCH64(name, ASM)                                                                  \
+    __global__ __launch_bounds__(256) void name(uint32_t* out, uint32_t a, uint32_t b) {    \
+        unsigned long long v[CH];                                                           \
+        for (int c = 0; c < CH; c++) v[c] = ((unsigned long long)a << 20) + threadIdx.x * 3 + c; \
+        unsigned long long w = ((unsigned long long)b << 33) + threadIdx.x;                 \
+        uint32_t w32 = (b + threadIdx.x) & 31;                                              \
+        for (int it = 0; it < ITER; it++) {                                                 \
+            _Pragma("unroll") for (int c = 0; c < CH; c++) asm volatile(ASM : "+v"(v[c]) : "v"(w), "s"(b), "v"(w32)); \
+        }                                                                                   \
+        unsigned long long acc = 0;                                                         \
+        for (int c = 0; c < CH; c++) acc ^= v[c];                                           \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)acc ^ (uint32_t)(acc >> 32); \
+    }
 
-template <typename T, typename K>
-void run(const char* name, K kern, int ops_per_iter_per_chain) {
-    T* d;
-    const int blocks = 256 * 8, threads = 256;
-    hipMalloc(&d, sizeof(T) * blocks * threads);
+BENCH32(k_xor, "v_xor_b32 %0, %0, %1")
+BENCH32(k_add, "v_add_u32 %0, %0, %1")
+BENCH32(k_shl, "v_lshlrev_b32 %0, %2, %0")
+BENCH32(k_and_or, "v_and_or_b32 %0, %0, %1, %1")
+BENCH32(k_or3, "v_or3_b32 %0, %0, %1, %1")
+BENCH32(k_lshl_or, "v_lshl_or_b32 %0, %0, 1, %1")
+BENCH32(k_add3, "v_add3_u32 %0, %0, %1, %1")
+BENCH32(k_xad, "v_xad_u32 %0, %0, %1, %1")
+BENCH32(k_bfe, "v_bfe_u32 %0, %0, 3, 5")
+BENCH32(k_bfi, "v_bfi_b32 %0, %1, %0, %1")
+BENCH32(k_alignbit, "v_alignbit_b32 %0, %0, %1, %2")
+BENCH32(k_ffbl, "v_ffbl_b32 %0, %0")
+BENCH32(k_ffbh, "v_ffbh_u32 %0, %0")
+BENCH32(k_bcnt, "v_bcnt_u32_b32 %0, %0, %1")
+BENCH32(k_min, "v_min_u32 %0, %0, %1")
+BENCH32(k_med3, "v_med3_i32 %0, %0, %1, %1")
+BENCH32(k_mul_lo, "v_mul_lo_u32 %0, %0, %1")
+BENCH32(k_mul24, "v_mul_u32_u24 %0, %0, %1")
+BENCH32(k_mad24, "v_mad_u32_u24 %0, %0, %1, %1")
+BENCH32(k_cmp_cnd, "v_cmp_lt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc")
+BENCH32(k_cndmask, "v_cndmask_b32 %0, %0, %1, vcc")
+BENCH32(k_not, "v_not_b32 %0, %0")
+BENCH32(k_mbcnt, "v_mbcnt_lo_u32_b32 %0, %1, %0")
+BENCH32(k_perm, "v_perm_b32 %0, %0, %1, %1")
+BENCH32(k_dpp_mov, "v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf")
+BENCH32(k_dpp_wave, "v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf")
+BENCH32(k_readlane, "v_readlane_b32 s20, %0, 3\n\tv_xor_b32 %0, s20, %0")
+BENCH64(k_shl64, "v_lshlrev_b64 %0, %2, %0")
+BENCH64(k_shr64, "v_lshrrev_b64 %0, %2, %0")
+BENCH64(k_shr64v, "v_lshrrev_b64 %0, %3, %0")
+BENCH64(k_add64, "v_lshl_add_u64 %0, %0, 0, %1")
+BENCH64(k_fma64, "v_fma_f64 %0, %0, %1, %1")
+BENCH64(k_mul64, "v_mul_f64 %0, %0, %1")
+BENCH64(k_cvt, "v_cvt_f64_i32 %0, %3")
+
+template <typename K>
+void run(const char* name, K kern, int instr_per_op) {
+    uint32_t* d;
+    const int blocks = 256 * 8, threads = 256; /* 8 waves per SIMD */
+    hipMalloc(&d, 4 * blocks * threads);
     hipEvent_t a, b;
     hipEventCreate(&a);
     hipEventCreate(&b);
-    kern<<<blocks, threads>>>(d, 3, (T)5);
+    kern<<<blocks, threads>>>(d, 5, 3);
     hipDeviceSynchronize();
     hipEventRecord(a);
-    kern<<<blocks, threads>>>(d, 3, (T)5);
+    kern<<<blocks, threads>>>(d, 5, 3);
     hipEventRecord(b);
     hipEventSynchronize(b);
     float ms;
     hipEventElapsedTime(&ms, a, b);
-    // wave-instructions executed per SIMD: blocks*4 waves / 1024 SIMDs, each ITER*CHAINS "ops"
-    double waves_per_simd = blocks * 4.0 / 1024.0;
-    double ops = waves_per_simd * ITER * CHAINS;
-    double cycles = ms * 1e-3 * 2.4e9;
-    printf("%-10s %8.3f ms  %6.2f cycles per source-level op per SIMD (at 2.4 GHz, %d ISA ops expected)\n", name, ms,
-           cycles / ops, ops_per_iter_per_chain);
+    const double ops = (blocks * 4.0 / 1024.0) * ITER * CH * instr_per_op; /* wave-instructions per SIMD */
+    printf("%-12s %8.3f ms  %6.2f cycles/instr/SIMD @2.4GHz\n", name, ms, ms * 1e-3 * 2.4e9 / ops);
     hipFree(d);
 }
 
 int main() {
-    run<uint32_t>("add32", k_add32, 1);
-    run<uint32_t>("xor+add32", k_xor32, 2);
-    run<uint32_t>("shl+add32", k_shl32, 2);
-    run<u64>("shl64+add", k_shl64, 3);
-    run<u64>("shr64v+add", k_shr64v, 4);
-    run<u64>("add64", k_add64, 2);
-    run<uint32_t>("ctz32+or+add", k_ctz32, 3);
-    run<u64>("ctz64+..", k_ctz64, 8);
-    run<uint32_t>("pop32+add", k_pop32, 2);
-    run<u64>("pop64+add", k_pop64, 4);
-    run<uint32_t>("mul32+add", k_mul32, 2);
-    run<uint32_t>("alignbit+add", k_alignbit, 2);
-    run<uint32_t>("cmp+cnd(+2)", k_cndmask, 4);
-    run<uint32_t>("min+add", k_min32, 2);
-    run<double>("fma64", k_fma64, 1);
-    run<double>("cvt64 x2+add", k_cvt64, 3);
-    run<uint32_t>("bfe+add+add", k_bfe, 3);
+#define R(k) run(#k, k, 1)
+    R(k_xor); R(k_add); R(k_shl); R(k_and_or); R(k_or3); R(k_lshl_or); R(k_add3); R(k_xad); R(k_bfe); R(k_bfi);
+    R(k_alignbit); R(k_ffbl); R(k_ffbh); R(k_bcnt); R(k_min); R(k_med3); R(k_mul_lo); R(k_mul24); R(k_mad24);
+    run("k_cmp_cnd", k_cmp_cnd, 2); R(k_cndmask); R(k_not); R(k_mbcnt); R(k_perm); R(k_dpp_mov); R(k_dpp_wave);
+    run("k_readlane", k_readlane, 2);
+    R(k_shl64); R(k_shr64); R(k_shr64v); R(k_add64); R(k_fma64); R(k_mul64); R(k_cvt);
     return 0;
 }
