@@ -49,6 +49,7 @@ struct TraceCell<64> {
 
 template <int W>
 struct TraceSink {
+    static constexpr bool kNeedsColumns = true;
     typename TraceCell<W>::T* trace;
     long n, i;
     template <typename WT>

@@ -1004,6 +1004,7 @@ struct BandWord<64> {
 };
 
 struct NoColumnSink {
+    static constexpr bool kNeedsColumns = false;
     template <typename WT>
     ASM_DEV void operator()(int, WT, WT) const {}
 };
@@ -1053,18 +1054,57 @@ ASM_DEV int nw_band(const uint32_t (&A0)[ND + 2], const uint32_t (&A1)[ND + 2], 
             sink(r + 1, VP, VN);
         }
     }
-    // columns C+1..n: slide one row per column; the reservoir's upper word is refilled every W slides
+    // columns C+1..n: slide one row per column; the reservoir's upper word is refilled every W slides.
+    if (Sink::kNeedsColumns) {
+        // plain form: every column's (VP, VN) in that column's own window coordinates, handed to the sink
 #pragma unroll
-    for (int bq = 0; bq < NBLK; bq++) {
-        const WT b0 = BLK(B0, bq), b1 = BLK(B1, bq);
-        const int r0 = bq == 0 ? C : 0;
-        int rend = nn - W * bq;
-        rend = rend > W ? W : rend;
-        for (int r = r0; r < rend; r++) {
-            if (r == C) hi0 = BLK(A0, bq + 1), hi1 = BLK(A1, bq + 1); /* wave-uniform */
-            NW_BAND_COLUMN(true, b0, b1, r)
-            sink(W * bq + r + 1, VP, VN);
+        for (int bq = 0; bq < NBLK; bq++) {
+            const WT b0 = BLK(B0, bq), b1 = BLK(B1, bq);
+            const int r0 = bq == 0 ? C : 0;
+            int rend = nn - W * bq;
+            rend = rend > W ? W : rend;
+            for (int r = r0; r < rend; r++) {
+                if (r == C) hi0 = BLK(A0, bq + 1), hi1 = BLK(A1, bq + 1); /* wave-uniform */
+                NW_BAND_COLUMN(true, b0, b1, r)
+                sink(W * bq + r + 1, VP, VN);
+            }
         }
+    } else if (nn > C) {
+        // Fused form (penalty only).  Algebraically the same recurrence: instead of producing a column's vertical deltas
+        // in its own window and shifting them for the next column, produce them directly in the NEXT column's window:
+        //   VPin' = HN | ~((D0 >> 1) | HP) | TOP ,  VNin' = HP & (D0 >> 1)
+        // (the "+1 for the row entering at the bottom" is the TOP bit; the "+1 above the window" is the zero shifted
+        // into D0 >> 1).  Three instructions fewer per column.  The bottom-row diagonal deltas are shifted into an
+        // accumulator and counted once per block instead of being added column by column.
+        WT VPin = (VP >> 1) | TOP, VNin = VN >> 1;
+#pragma unroll
+        for (int bq = 0; bq < NBLK; bq++) {
+            const WT b0 = BLK(B0, bq), b1 = BLK(B1, bq);
+            const int r0 = bq == 0 ? C : 0;
+            int rend = nn - W * bq;
+            rend = rend > W ? W : rend;
+            WT acc = 0;
+            for (int r = r0; r < rend; r++) {
+                if (r == C) hi0 = BLK(A0, bq + 1), hi1 = BLK(A1, bq + 1); /* wave-uniform */
+                lo0 = (lo0 >> 1) | (hi0 << (W - 1)), hi0 >>= 1;
+                lo1 = (lo1 >> 1) | (hi1 << (W - 1)), hi1 >>= 1;
+                const WT T0 = (WT)0 - ((b0 >> r) & (WT)1);
+                const WT T1 = (WT)0 - ((b1 >> r) & (WT)1);
+                const WT Eq = ~((lo0 ^ T0) | (lo1 ^ T1));
+                const WT D0 = ((((Eq & VPin) + VPin) ^ VPin) | Eq) | VNin;
+                const WT HP = VNin | ~(D0 | VPin);
+                const WT HN = VPin & D0;
+                acc = (acc << 1) | (D0 >> (W - 1));
+                const WT D0s = D0 >> 1;
+                VPin = HN | ~(D0s | HP) | TOP;
+                VNin = HP & D0s;
+            }
+            if (rend > r0) S += (rend - r0) - (W == 32 ? __popc((uint32_t)acc) : __popcll((u64)acc));
+        }
+        // back to the last column's own window: VP = VPin << 1 (its bit 0 is always 0); VN = VNin << 1 | D0[0] — only
+        // the bits above row m are needed below, and bit 0 never is
+        VP = VPin << 1;
+        VN = VNin << 1;
     }
 #undef NW_BAND_COLUMN
 #undef BLK
