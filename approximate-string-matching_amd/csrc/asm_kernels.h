@@ -1011,6 +1011,18 @@ struct NoColumnSink {
 
 // `sink(j, VP, VN)` sees the vertical delta vectors of every finished column j (1-based, in that column's window
 // coordinates); the traceback of asm_cover.h stores them.
+// all-ones / all-zeros word from bit r of the text block (one v_bfe_i32 for the 32-bit window)
+template <int W>
+ASM_DEV typename BandWord<W>::T band_text_bit(typename BandWord<W>::T b, int r);
+template <>
+ASM_DEV uint32_t band_text_bit<32>(uint32_t b, int r) {
+    return (uint32_t)__builtin_amdgcn_sbfe((int)b, r, 1);
+}
+template <>
+ASM_DEV u64 band_text_bit<64>(u64 b, int r) {
+    return 0ull - ((b >> r) & 1ull);
+}
+
 template <int ND, int W, typename Sink = NoColumnSink> /* ND = plane dwords per string (4 * w4); A arrays carry two zero dwords of padding */
 ASM_DEV int nw_band(const uint32_t (&A0)[ND + 2], const uint32_t (&A1)[ND + 2], const uint32_t (&B0)[ND],
                     const uint32_t (&B1)[ND], int m, int nn, const Sink& sink = Sink()) {
@@ -1084,20 +1096,26 @@ ASM_DEV int nw_band(const uint32_t (&A0)[ND + 2], const uint32_t (&A1)[ND + 2], 
             int rend = nn - W * bq;
             rend = rend > W ? W : rend;
             WT acc = 0;
-            for (int r = r0; r < rend; r++) {
-                if (r == C) hi0 = BLK(A0, bq + 1), hi1 = BLK(A1, bq + 1); /* wave-uniform */
-                lo0 = (lo0 >> 1) | (hi0 << (W - 1)), hi0 >>= 1;
-                lo1 = (lo1 >> 1) | (hi1 << (W - 1)), hi1 >>= 1;
-                const WT T0 = (WT)0 - ((b0 >> r) & (WT)1);
-                const WT T1 = (WT)0 - ((b1 >> r) & (WT)1);
-                const WT Eq = ~((lo0 ^ T0) | (lo1 ^ T1));
-                const WT D0 = ((((Eq & VPin) + VPin) ^ VPin) | Eq) | VNin;
-                const WT HP = VNin | ~(D0 | VPin);
-                const WT HN = VPin & D0;
-                acc = (acc << 1) | (D0 >> (W - 1));
-                const WT D0s = D0 >> 1;
-                VPin = HN | ~(D0s | HP) | TOP;
-                VNin = HP & D0s;
+            // the block's columns in two runs, [r0, C) and [C, rend): the reservoir's upper word is refilled between
+            // them, which keeps the refill out of the per-column code
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const int ra = half == 0 ? r0 : (r0 > C ? r0 : C);
+                const int rb = half == 0 ? (rend < C ? rend : C) : rend;
+                if (half == 1) hi0 = BLK(A0, bq + 1), hi1 = BLK(A1, bq + 1);
+                for (int r = ra; r < rb; r++) {
+                    lo0 = (lo0 >> 1) | (hi0 << (W - 1)), hi0 >>= 1;
+                    lo1 = (lo1 >> 1) | (hi1 << (W - 1)), hi1 >>= 1;
+                    const WT T0 = band_text_bit<W>(b0, r), T1 = band_text_bit<W>(b1, r);
+                    const WT Eq = ~((lo0 ^ T0) | (lo1 ^ T1));
+                    const WT D0 = ((((Eq & VPin) + VPin) ^ VPin) | Eq) | VNin;
+                    const WT HP = VNin | ~(D0 | VPin);
+                    const WT HN = VPin & D0;
+                    acc = (acc << 1) | (D0 >> (W - 1));
+                    const WT D0s = D0 >> 1;
+                    VPin = HN | ~(D0s | HP) | TOP;
+                    VNin = HP & D0s;
+                }
             }
             if (rend > r0) S += (rend - r0) - (W == 32 ? __popc((uint32_t)acc) : __popcll((u64)acc));
         }
