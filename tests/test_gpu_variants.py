@@ -1,0 +1,59 @@
+"""Every kernel family stays parity-green, not only the default dispatch: the A/B switches of the C-ABI library
+(environment variables read at asm_create) select the alternative kernels — one-pair-per-thread Greedy, lane-refilling
+LEAP, unsorted LEAP, full-height NW, workgroup-per-pair wide kernels, unbucketed batches — and each is checked against the
+oracle in a fresh process."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+import approximate_string_matching_amd as asm
+from tests import oracle_binding
+orc = oracle_binding.load_oracle()
+eng = asm.Engine(0)
+def check(name, got, want):
+    bad = int((got != want).sum())
+    assert bad == 0, (name, bad)
+for wl, n, k in (("C2", 12000, 3), ("C5", 6000, 3), ("C3", 1500, 30), ("C2", 2000, 10)):
+    cfg, _, _ = asm.workload(wl)
+    hb = asm.generate_pairs(cfg, 77, n)
+    p = asm.Params.default(k=k)
+    b = eng.upload(hb, asm.GREEDY_SEQUENTIAL)
+    d = [eng.malloc(4 * n) for _ in range(3)]
+    d_cnt = eng.malloc(32)
+    eng.memset_async(d_cnt, 0, 32)
+    eng.run_benchmark_async(b, p, d[0], d[1], d[2], d_cnt, repack=True)
+    check(wl + " nw", eng.to_host(d[0], n), orc.nw(hb))
+    check(wl + " leap", eng.to_host(d[1], n), orc.leap(hb, k=k))
+    check(wl + " greedy", eng.to_host(d[2], n), orc.greedy(hb, k=k, mode=0))
+    cost, cig, _ = eng.greedy_with_cigar(b, p, cap=96)
+    want_cost, want_cig = orc.greedy(hb, k=k, mode=0, cigars=True)
+    check(wl + " cigar cost", cost, want_cost)
+    assert cig == want_cig, wl
+print("ok")
+""" % ROOT
+
+
+@pytest.mark.parametrize("env", [
+    {"ASM_PERSIST": "0"},
+    {"ASM_PERSIST_LEAP": "1", "ASM_LEAP_HINT": "0"},
+    {"ASM_LEAP_HINT": "0"},
+    {"ASM_NW_BANDED": "0"},
+    {"ASM_WAVE": "0"},
+    {"ASM_BUCKET": "0"},
+    {"ASM_REFILL_GREEDY": "1", "ASM_REFILL_LEAP": "64", "ASM_PERSIST_LEAP": "1", "ASM_LEAP_HINT": "0"},
+])
+def test_alternative_kernels_match_the_oracle(env):
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, "-c", SCRIPT], env=e, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (env, out.stdout[-500:], out.stderr[-1500:])
