@@ -490,15 +490,21 @@ def allreduce_counters(counters, dist=None):
 
 
 def gather_penalties(local, dist=None, dst: int = 0):
-    """Optional: collect per-shard penalty tensors on rank `dst` (direct peer links; no ring needed)."""
+    """Optional: collect the per-shard penalty tensors on rank `dst` (each peer sends over its own direct link; shards
+    may differ in length by one pair).  Returns the list of shards on `dst`, None elsewhere."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return [local]
-    out = [None] * dist.get_world_size() if dist.get_rank() == dst else None
     import torch
 
-    sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(dist.get_world_size())]
+    world = dist.get_world_size()
+    sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
     dist.all_gather(sizes, torch.tensor([local.numel()], dtype=torch.int64, device=local.device))
-    if dist.get_rank() == dst:
-        out = [torch.empty(int(s.item()), dtype=local.dtype, device=local.device) for s in sizes]
-    dist.gather(local, out, dst=dst) if all(int(s.item()) == local.numel() for s in sizes) else None
-    return out
+    longest = max(int(s.item()) for s in sizes)
+    padded = torch.zeros(longest, dtype=local.dtype, device=local.device)
+    padded[:local.numel()] = local
+    bufs = [torch.empty(longest, dtype=local.dtype, device=local.device) for _ in range(world)] \
+        if dist.get_rank() == dst else None
+    dist.gather(padded, bufs, dst=dst)
+    if dist.get_rank() != dst:
+        return None
+    return [b[:int(s.item())] for b, s in zip(bufs, sizes)]

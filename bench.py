@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the workload's batch, capped 1e6)")
+    ap.add_argument("--total-pairs", type=int, default=0,
+                    help="strong scaling: this many pairs in total, split into contiguous shards over the ranks "
+                         "(e.g. --workload C4 --total-pairs 10000000); default is weak scaling with --pairs per GPU")
     ap.add_argument("--cpu-sample", type=int, default=300_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -82,10 +85,14 @@ def main():
 
     cfg, n_default, params = asm.workload(args.workload)
     n = args.pairs or min(n_default, 1_000_000)
+    first = asm.weak_shard_first(rank, n)
+    if args.total_pairs:
+        lo, hi = asm.shard_bounds(args.total_pairs, world, rank)
+        first, n = lo, hi - lo
     eng = asm.Engine(local_rank)
     # everything (kernels, counters, the all-reduce) is ordered on torch's current stream
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
-    batch = eng.generate(cfg, rank * n, n)  # this rank's shard of the seeded stream, straight into HBM
+    batch = eng.generate(cfg, first, n)  # this rank's shard of the seeded stream, straight into HBM
     aligners = [asm.NW, asm.LEAP, asm.GREEDY] if args.workload != "C3" else [asm.LEAP, asm.GREEDY]
     d_pen = {a: eng.malloc(4 * n) for a in aligners}
     counters = torch.zeros(4, dtype=torch.int64, device="cuda")  # total, nw_ok, leap_ok, greedy_ok
@@ -148,7 +155,7 @@ def main():
                     "undetermined_pairs": cov["undetermined"],
                     "note": "NW traceback tie-break is this library's (parasail's is unpinned); README.md:36 reports 94.213"}
     if rank == 0:
-        total_pairs = world * n * args.steps
+        total_pairs = (args.total_pairs if args.total_pairs else world * n) * args.steps
         value = total_pairs / elapsed
         hb = batch.download()
         m_len, n_len = hb.lengths()
@@ -167,7 +174,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.total_pairs else "weak",
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",

@@ -35,7 +35,7 @@ def _worker(rank, world, port, total, q):
 
 
 def test_two_rank_sharding_and_counter_allreduce(asm, oracle):
-    total, world, port = 3000, 2, 29500 + os.getpid() % 2000
+    total, world, port = 3001, 2, 29500 + os.getpid() % 2000
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
