@@ -113,6 +113,9 @@ def load_library() -> ctypes.CDLL:
         "asm_generate_pairs": (i32, [c.POINTER(GenConfig), i64, i64, vp, vp, vp, c.c_size_t, vp, c.c_size_t]),
         "asm_batch_upload": (i32, [vp, i64, vp, vp, vp, vp, i32, c.POINTER(vp)]),
         "asm_batch_generate": (i32, [vp, c.POINTER(GenConfig), i64, i64, i32, c.POINTER(vp)]),
+        "asm_reference_upload": (i32, [vp, vp, c.c_size_t, c.POINTER(vp)]),
+        "asm_reference_free": (i32, [vp, vp]),
+        "asm_batch_from_hits": (i32, [vp, vp, i64, vp, vp, vp, i32, c.POINTER(vp)]),
         "asm_batch_free": (i32, [vp, vp]),
         "asm_batch_size": (i64, [vp]),
         "asm_batch_max_length": (i32, [vp]),
@@ -260,6 +263,24 @@ class DeviceBatch:
             pass
 
 
+class Reference:
+    """asm_reference: a reference text resident in HBM."""
+
+    def __init__(self, engine: "Engine", ptr, length: int):
+        self.engine, self.ptr, self.length = engine, ptr, length
+
+    def free(self) -> None:
+        if self.ptr:
+            self.engine.lib.asm_reference_free(self.engine.h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class Engine:
     """asm_handle: one per GPU.  All device work of the hot path goes through here."""
 
@@ -307,6 +328,24 @@ class Engine:
     def generate(self, cfg: GenConfig, first: int, n: int, greedy_mode: int = GREEDY_CLEAN) -> DeviceBatch:
         ptr = ctypes.c_void_p()
         self._chk(self.lib.asm_batch_generate(self.h, ctypes.byref(cfg), first, n, greedy_mode, ctypes.byref(ptr)))
+        return DeviceBatch(self, ptr)
+
+    def upload_reference(self, text) -> "Reference":
+        """Reference text (bytes / str / uint8 array) resident in HBM for seed-hit batches."""
+        buf = np.frombuffer(text.encode("ascii") if isinstance(text, str) else bytes(text), np.uint8)
+        ptr = ctypes.c_void_p()
+        self._chk(self.lib.asm_reference_upload(self.h, buf.ctypes.data, buf.size, ctypes.byref(ptr)))
+        return Reference(self, ptr, buf.size)
+
+    def batch_from_hits(self, ref: "Reference", reads: np.ndarray, read_off: np.ndarray, hit_pos: np.ndarray,
+                        greedy_mode: int = GREEDY_CLEAN) -> DeviceBatch:
+        """The mapper's call shape (GASMA/mapper/main.cpp:77-86): pair i = (read i, reference window at hit_pos[i])."""
+        reads = np.ascontiguousarray(reads, np.uint8)
+        ro = np.ascontiguousarray(read_off, np.uint32)
+        pos = np.ascontiguousarray(hit_pos, np.uint64)
+        ptr = ctypes.c_void_p()
+        self._chk(self.lib.asm_batch_from_hits(self.h, ref.ptr, ro.size - 1, reads.ctypes.data, ro.ctypes.data,
+                                               pos.ctypes.data, greedy_mode, ctypes.byref(ptr)))
         return DeviceBatch(self, ptr)
 
     def pack_async(self, batch: DeviceBatch) -> None:

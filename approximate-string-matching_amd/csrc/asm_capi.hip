@@ -65,6 +65,11 @@ struct asm_batch {
     PackBuckets pb;
 };
 
+struct asm_reference {
+    char* d_text = nullptr;
+    size_t len = 0;
+};
+
 static thread_local std::string g_err;
 
 static int fail(asm_handle* h, int code, const std::string& msg) {
@@ -589,6 +594,106 @@ int asm_batch_generate(asm_handle* h, const asm_gen_config* cfg, int64_t first, 
     (void)hipFree(d_m);
     (void)hipFree(d_n);
     (void)hipFree(d_max);
+    (void)hipFree(d_tmp);
+    if (rc) {
+        batch_release(b);
+        return rc;
+    }
+    *out = b;
+    return ASM_OK;
+}
+
+int asm_reference_upload(asm_handle* h, const char* text, size_t len, asm_reference** out) {
+    if (!h || !out || (!text && len)) return fail(h, ASM_EINVAL, "asm_reference_upload: bad argument");
+    *out = nullptr;
+    HIPCHK(h, hipSetDevice(h->device));
+    asm_reference* r = new asm_reference;
+    r->len = len;
+    if (hipMalloc((void**)&r->d_text, len + 16) != hipSuccess) {
+        delete r;
+        return fail(h, ASM_ENOMEM, "asm_reference_upload: hipMalloc failed");
+    }
+    if (len && hipMemcpy(r->d_text, text, len, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(r->d_text);
+        delete r;
+        return fail(h, ASM_ENODEVICE, "asm_reference_upload: copy failed");
+    }
+    *out = r;
+    return ASM_OK;
+}
+
+int asm_reference_free(asm_handle* h, asm_reference* r) {
+    if (h) (void)hipSetDevice(h->device);
+    if (r) {
+        (void)hipFree(r->d_text);
+        delete r;
+    }
+    return ASM_OK;
+}
+
+int asm_batch_from_hits(asm_handle* h, const asm_reference* ref, int64_t n, const char* reads, const uint32_t* read_off,
+                        const uint64_t* hit_pos, int greedy_mode, asm_batch** out) {
+    if (!h || !ref || !out || n < 0 || !read_off || (n > 0 && (!reads || !hit_pos)))
+        return fail(h, ASM_EINVAL, "asm_batch_from_hits: bad arguments");
+    if (greedy_mode != ASM_GREEDY_CLEAN && greedy_mode != ASM_GREEDY_SEQUENTIAL)
+        return fail(h, ASM_EINVAL, "asm_batch_from_hits: unknown greedy_mode");
+    *out = nullptr;
+    HIPCHK(h, hipSetDevice(h->device));
+    int maxlen = 0;
+    for (int64_t i = 0; i < n; i++) {
+        if (read_off[i + 1] < read_off[i]) return fail(h, ASM_EINVAL, "asm_batch_from_hits: offsets must be non-decreasing");
+        const int m = (int)(read_off[i + 1] - read_off[i]);
+        maxlen = m > maxlen ? m : maxlen;
+    }
+    if (maxlen + 1 > ASM_MAX_LENGTH) return fail(h, ASM_EUNSUPPORTED, "asm_batch_from_hits: a read is longer than ASM_MAX_LENGTH - 1");
+    asm_batch* b = new asm_batch;
+    b->n = n;
+    b->maxlen = maxlen + 1; /* the window is one base longer than the read (mapper/main.cpp:80) */
+    b->greedy_mode = greedy_mode;
+    b->reads_bytes = n ? read_off[n] : 0;
+    unsigned long long* d_pos = nullptr;
+    uint32_t* d_wl = nullptr;
+    void* d_tmp = nullptr;
+    int rc = ASM_OK;
+    do {
+#define TRY(call)                                                        \
+    if ((call) != hipSuccess) {                                          \
+        rc = fail(h, ASM_ENODEVICE, std::string(#call) + " failed");     \
+        break;                                                           \
+    }
+        const size_t cnt = (size_t)n + 1;
+        TRY(hipMalloc((void**)&b->d_reads, b->reads_bytes + 16));
+        TRY(hipMalloc((void**)&b->d_read_off, sizeof(uint32_t) * cnt));
+        TRY(hipMalloc((void**)&b->d_ref_off, sizeof(uint32_t) * cnt));
+        TRY(hipMalloc((void**)&d_pos, sizeof(unsigned long long) * cnt));
+        TRY(hipMalloc((void**)&d_wl, sizeof(uint32_t) * cnt));
+        TRY(hipMemcpyAsync(b->d_reads, reads, b->reads_bytes, hipMemcpyHostToDevice, h->stream));
+        TRY(hipMemcpyAsync(b->d_read_off, read_off, sizeof(uint32_t) * cnt, hipMemcpyHostToDevice, h->stream));
+        if (n) TRY(hipMemcpyAsync(d_pos, hit_pos, sizeof(unsigned long long) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(hit_window_lengths_kernel, dim3(grid_for(n + 1)), dim3(ASM_BLOCK), 0, h->stream, b->d_read_off,
+                           d_pos, (unsigned long long)ref->len, (long)n, d_wl);
+        TRY(hipGetLastError());
+        size_t tmp_bytes = 0;
+        TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_wl, b->d_ref_off, (int)cnt, h->stream));
+        TRY(hipMalloc(&d_tmp, tmp_bytes + 16));
+        TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_wl, b->d_ref_off, (int)cnt, h->stream));
+        uint32_t total = 0;
+        TRY(hipMemcpyAsync(&total, b->d_ref_off + n, 4, hipMemcpyDeviceToHost, h->stream));
+        TRY(hipStreamSynchronize(h->stream));
+        b->refs_bytes = total;
+        TRY(hipMalloc((void**)&b->d_refs, b->refs_bytes + 16));
+        if (n) {
+            int64_t blocks = (n + 3) / 4;
+            blocks = blocks > 256 * 16 ? 256 * 16 : blocks;
+            hipLaunchKernelGGL(hit_window_gather_kernel, dim3((unsigned)blocks), dim3(ASM_BLOCK), 0, h->stream, ref->d_text,
+                               d_pos, b->d_ref_off, (long)n, b->d_refs);
+            TRY(hipGetLastError());
+        }
+#undef TRY
+        rc = batch_finish(h, b);
+    } while (0);
+    (void)hipFree(d_pos);
+    (void)hipFree(d_wl);
     (void)hipFree(d_tmp);
     if (rc) {
         batch_release(b);

@@ -1178,6 +1178,43 @@ __global__ __launch_bounds__(ASM_BLOCK) void nw_banded_kernel(const uint4* __res
     out.put(i, result);
 }
 
+// --------------------------------------------------------------------------------------------------------
+// Seed-hit batches, the shape of the reference's read mapper (GASMA/mapper/main.cpp:77-86): for a hit of read i at
+// reference position p the aligner sees reference[start, start + len_i + 1) with start = p ? p - 1 : 0 (clipped at
+// the reference's end).  The reference text stays resident in HBM; windows are gathered on the device.
+// --------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ASM_BLOCK) void hit_window_lengths_kernel(const uint32_t* __restrict__ read_off,
+                                                                       const unsigned long long* __restrict__ hit_pos,
+                                                                       unsigned long long ref_len, long n,
+                                                                       uint32_t* __restrict__ win_len) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) {
+        win_len[n] = 0u; /* so that an exclusive scan over n+1 entries yields the total */
+        return;
+    }
+    const unsigned long long p = hit_pos[i];
+    const unsigned long long start = p ? p - 1ull : 0ull;
+    const unsigned long long want = (unsigned long long)(read_off[i + 1] - read_off[i]) + 1ull;
+    const unsigned long long room = start < ref_len ? ref_len - start : 0ull;
+    win_len[i] = (uint32_t)(want < room ? want : room);
+}
+
+__global__ __launch_bounds__(ASM_BLOCK) void hit_window_gather_kernel(const char* __restrict__ reference,
+                                                                      const unsigned long long* __restrict__ hit_pos,
+                                                                      const uint32_t* __restrict__ ref_off, long n,
+                                                                      char* __restrict__ refs) {
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long i = wave; i < n; i += nwaves) { /* one wave per hit: 64 contiguous bytes per load */
+        const unsigned long long p = hit_pos[i];
+        const unsigned long long start = p ? p - 1ull : 0ull;
+        const uint32_t o = ref_off[i], len = ref_off[i + 1] - o;
+        for (uint32_t q = (uint32_t)lane; q < len; q += 64u) refs[o + q] = reference[start + q];
+    }
+}
+
 // accuracy counters (benchmark_utils.h:249-255).  A single hot word saturates at ~88 atomics/us on this chip
 // (MI355X_MICROARCH.md "dequeue"), so: wave shuffle -> LDS -> ONE atomic per workgroup, and a small grid.
 ASM_DEV unsigned int block_sum_256(unsigned int v, unsigned int* s_part /* [4] */) {

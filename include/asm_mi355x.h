@@ -101,6 +101,15 @@ int asm_batch_upload(asm_handle* h, int64_t n, const char* reads, const uint32_t
  * to asm_generate_pairs) and packs them: no PCIe traffic. */
 int asm_batch_generate(asm_handle* h, const asm_gen_config* cfg, int64_t first, int64_t n, int greedy_mode,
                        asm_batch** out);
+/* Seed-hit batches — the shape in which the reference's read mapper calls the Greedy aligner (GASMA/mapper/main.cpp:
+ * 67-96): the reference text is uploaded once and stays in HBM; for hit i of read i at 0-based reference position
+ * hit_pos[i] the pair is (read i, reference[start, start + len_i + 1)) with start = hit_pos ? hit_pos - 1 : 0, clipped at
+ * the reference's end (mapper/main.cpp:79-80).  Windows are gathered on the device.  MAPQ = 60 + Greedy cost (:95). */
+typedef struct asm_reference asm_reference;
+int asm_reference_upload(asm_handle* h, const char* text, size_t len, asm_reference** out);
+int asm_reference_free(asm_handle* h, asm_reference* r);
+int asm_batch_from_hits(asm_handle* h, const asm_reference* ref, int64_t n, const char* reads, const uint32_t* read_off,
+                        const uint64_t* hit_pos, int greedy_mode, asm_batch** out);
 int asm_batch_free(asm_handle* h, asm_batch* b);
 int64_t asm_batch_size(const asm_batch* b);
 int asm_batch_max_length(const asm_batch* b);

@@ -284,3 +284,35 @@ def test_leap_work_hint_changes_schedule_not_results(asm, engine, oracle):
         engine.align_hinted_async(batch, asm.LEAP, params, d_nw, d_leap)
         _check("hinted by junk", engine.to_host(d_leap, n), want, hb)
         engine.free(d_nw), engine.free(d_leap)
+
+
+def test_seed_hit_batches_mapper_shape(asm, engine, oracle):
+    """The reference mapper's call shape (GASMA/mapper/main.cpp:67-96): resident reference text, one Greedy alignment per
+    seed hit against reference[start, start + len + 1), start = pos ? pos - 1 : 0; MAPQ = 60 + cost."""
+    rng = np.random.default_rng(11)
+    genome = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 200_000)]
+    n, L = 5000, 100
+    pos = rng.integers(0, genome.size - L, n).astype(np.uint64)
+    pos[:4] = [0, 1, genome.size - L, genome.size - L - 1]  # both ends of the reference
+    reads = np.empty((n, L), np.uint8)
+    for i in range(n):
+        r = genome[int(pos[i]):int(pos[i]) + L].copy()
+        for _ in range(int(rng.integers(0, 5))):
+            r[int(rng.integers(0, L))] = b"ACGT"[int(rng.integers(0, 4))]
+        reads[i] = r
+    read_off = (np.arange(n + 1) * L).astype(np.uint32)
+    ref = engine.upload_reference(genome.tobytes())
+    batch = engine.batch_from_hits(ref, reads.reshape(-1), read_off, pos)
+    # the same pairs built explicitly on the host
+    pairs = []
+    for i in range(n):
+        start = int(pos[i]) - 1 if pos[i] else 0
+        pairs.append((reads[i].tobytes().decode(), genome[start:start + L + 1].tobytes().decode()))
+    hb = asm.HostBatch.from_strings(pairs)
+    got = batch.download()
+    assert np.array_equal(got.refs, hb.refs) and np.array_equal(got.ref_off, hb.ref_off)
+    params = asm.Params.default(k=3)
+    cost = engine.align(batch, asm.GREEDY, params)
+    _check("mapper greedy", cost, oracle.greedy(hb, k=3, mode=1), hb)
+    mapq = 60 + cost
+    assert mapq.min() >= 60
