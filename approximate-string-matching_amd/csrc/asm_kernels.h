@@ -76,13 +76,17 @@ ASM_DEV void pack_convert(const uint32_t* sb, uint32_t b0, int len, int w4, int 
                         const int rem = len - (cbase + 4 * q);
                         const uint32_t vm = rem >= 4 ? ~0u : (rem <= 0 ? 0u : (0xffffffffu >> (32 - 8 * rem)));
                         ch &= vm;
-                        const uint32_t x = ch ^ 0x43434343u; /* 'C' */
-                        const uint32_t fC = swar_zero_bytes(x);
-                        const uint32_t fG = swar_zero_bytes(x ^ 0x04040404u); /* 'G' = 'C' ^ 0x04 */
-                        const uint32_t fT = swar_zero_bytes(x ^ 0x17171717u); /* 'T' = 'C' ^ 0x17 */
+                        // Four characters at once.  Bits 1-2 of 'A','C','T','G' are 0,1,2,3: use them as a v_perm_b32
+                        // selector into the table "ACTG" to get the one base each byte could be, and accept the byte
+                        // only if it IS that base (exactly 'C','G','T' set plane bits; any other byte, NUL included,
+                        // is code 00 as in bit_convert.cpp:340-355).  plane1 (G|T) = bit 2, plane0 (C|T) = bit 1 ^ bit 2.
+                        const uint32_t half = ch >> 1;
+                        const uint32_t canon = __builtin_amdgcn_perm(0u, 0x47544341u, half & 0x03030303u);
+                        const uint32_t ok = swar_zero_bytes(canon ^ ch); /* bit 7 of every byte that is a real base */
+                        const uint32_t f0 = ((ch ^ half) << 6) & ok, f1 = (ch << 5) & ok;
                         /* gather the four byte flags (bits 7,15,23,31) into a nibble */
-                        q0[w] |= (((fC | fT) * 0x00204081u) >> 28) << (4 * q);
-                        q1[w] |= (((fG | fT) * 0x00204081u) >> 28) << (4 * q);
+                        q0[w] |= ((f0 * 0x00204081u) >> 28) << (4 * q);
+                        q1[w] |= ((f1 * 0x00204081u) >> 28) << (4 * q);
                     }
                 }
             }

@@ -316,3 +316,27 @@ def test_seed_hit_batches_mapper_shape(asm, engine, oracle):
     _check("mapper greedy", cost, oracle.greedy(hb, k=3, mode=1), hb)
     mapq = 60 + cost
     assert mapq.min() >= 60
+
+
+def test_pack_maps_every_non_base_byte_to_code_00(asm, engine, oracle):
+    """Only exact 'C','G','T' set plane bits; 'N', lower case, punctuation, 0x01..0xff all collapse onto 'A'
+    (bit_convert.cpp:340-355).  Checked through Greedy, whose oracle applies the same rule byte by byte."""
+    rng = np.random.default_rng(3)
+    pool = np.array(list(b"ACGTACGTACGTNnacgt-*BDEFHU@") + [1, 2, 0x42, 0x44, 0x53, 0x55, 0x7f, 0xc3, 0xd4, 0xff], np.uint8)
+    n = 4000
+    lens_a = rng.integers(1, 200, n)
+    lens_b = np.clip(lens_a + rng.integers(-3, 4, n), 1, None)
+    reads = pool[rng.integers(0, pool.size, int(lens_a.sum()))]
+    refs = pool[rng.integers(0, pool.size, int(lens_b.sum()))]
+    ro = np.zeros(n + 1, np.uint32); ro[1:] = np.cumsum(lens_a)
+    fo = np.zeros(n + 1, np.uint32); fo[1:] = np.cumsum(lens_b)
+    # make the pairs related so that Greedy takes real steps
+    for i in range(n):
+        k = min(lens_a[i], lens_b[i])
+        refs[fo[i]:fo[i] + k] = reads[ro[i]:ro[i] + k]
+        for _ in range(3):
+            refs[fo[i] + int(rng.integers(0, k))] = pool[int(rng.integers(0, pool.size))]
+    hb = asm.HostBatch(reads, ro, refs, fo)
+    for mode in (asm.GREEDY_CLEAN, asm.GREEDY_SEQUENTIAL):
+        got = engine.align(engine.upload(hb, mode), asm.GREEDY, asm.Params.default(k=3))
+        _check("greedy on dirty alphabet", got, oracle.greedy(hb, k=3, mode=mode), hb)
