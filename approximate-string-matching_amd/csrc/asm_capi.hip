@@ -22,6 +22,9 @@ struct asm_handle {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr;    /* asm_run_benchmark_async runs Greedy beside the NW -> LEAP chain */
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool overlap = true;                  /* ASM_OVERLAP=0: everything on one stream */
     std::string err;
     int num_cus = 256;
     bool persist = true;                  /* Greedy: lane-refilling persistent kernel (ASM_PERSIST=0 disables) */
@@ -203,6 +206,9 @@ int asm_create(asm_handle** out, int device) {
     HIPCHK(h, hipSetDevice(device));
     HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
+    HIPCHK(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     hipDeviceProp_t prop;
     HIPCHK(h, hipGetDeviceProperties(&prop, device));
     h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -210,6 +216,7 @@ int asm_create(asm_handle** out, int device) {
     const char* env = getenv("ASM_PERSIST");
     h->persist = !(env && env[0] == '0');
     if ((env = getenv("ASM_PERSIST_LEAP"))) h->persist_leap = env[0] != '0';
+    if ((env = getenv("ASM_OVERLAP"))) h->overlap = env[0] != '0';
     if ((env = getenv("ASM_LEAP_HINT"))) h->leap_hint = env[0] != '0';
     if ((env = getenv("ASM_BUCKET"))) h->bucketing = env[0] != '0';
     if ((env = getenv("ASM_WAVE"))) h->wave_kernels = env[0] != '0';
@@ -224,6 +231,9 @@ int asm_destroy(asm_handle* h) {
     if (!h) return ASM_OK;
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     (void)hipFree(h->d_work);
     delete h;
     return ASM_OK;
@@ -974,10 +984,26 @@ int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, in
     if (!h || !b || !p) return fail(h, ASM_EINVAL, "asm_run_benchmark_async: NULL argument");
     int rc = ASM_OK;
     if (repack) rc = asm_batch_pack_async(h, b);
+    // Greedy depends only on the packed planes, NW -> LEAP form their own chain (LEAP is scheduled by the NW penalties):
+    // run Greedy on a side stream so that the two chains fill each other's launch gaps and tail waves.
+    const bool fork = h->overlap && d_greedy && (d_nw || d_leap) && !rc;
+    hipStream_t main_stream = h->stream;
+    if (fork) {
+        HIPCHK(h, hipEventRecord(h->ev_fork, main_stream));
+        HIPCHK(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+        h->stream = h->side_stream;
+        rc = asm_align_batch_async(h, b, ASM_GREEDY, p, d_greedy);
+        h->stream = main_stream;
+        if (!rc) HIPCHK(h, hipEventRecord(h->ev_join, h->side_stream));
+    }
     if (!rc && d_nw) rc = asm_align_batch_async(h, b, ASM_NW, p, d_nw);
     /* LEAP is scheduled by the NW penalties just computed (same work, sorted inside each workgroup) */
     if (!rc && d_leap) rc = asm_align_batch_hinted_async(h, b, ASM_LEAP, p, d_nw, d_leap);
-    if (!rc && d_greedy) rc = asm_align_batch_async(h, b, ASM_GREEDY, p, d_greedy);
+    if (fork) {
+        if (!rc) HIPCHK(h, hipStreamWaitEvent(main_stream, h->ev_join, 0));
+    } else if (!rc && d_greedy) {
+        rc = asm_align_batch_async(h, b, ASM_GREEDY, p, d_greedy);
+    }
     if (!rc && d_counters && d_nw) rc = asm_accuracy_async(h, d_nw, d_leap, d_greedy, d_answers, b->n, d_counters);
     return rc;
 }
