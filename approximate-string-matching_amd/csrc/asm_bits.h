@@ -30,27 +30,25 @@ ASM_DEV V128 v_xor(V128 a, V128 b) { return v_make(a.lo ^ b.lo, a.hi ^ b.hi); }
 ASM_DEV V128 v_not(V128 a) { return v_make(~a.lo, ~a.hi); }
 
 // utils.h:143-153 "shift_left": bits move toward index 0; 0 for s outside [0,127].
+// Two stages: a 128-bit funnel shift by s mod 64 (the hardware takes 64-bit shift counts mod 64, and "<< (63 - r) << 1"
+// is a shift by 64 - r that is also right for r = 0), then a word move when s >= 64.
 ASM_DEV V128 v_toward0(V128 v, int s) {
-    const bool dead = (unsigned)s >= 128u;
-    const bool big = s >= 64;
     const int r = s & 63;
-    const u64 a = big ? v.hi : v.lo;
-    const u64 b = big ? 0ull : v.hi;
-    u64 lo = (a >> r) | (r ? (b << (64 - r)) : 0ull);
-    u64 hi = b >> r;
-    return v_make(dead ? 0ull : lo, dead ? 0ull : hi);
+    const u64 lo1 = (v.lo >> r) | ((v.hi << (63 - r)) << 1);
+    const u64 hi1 = v.hi >> r;
+    const bool big = (s & 64) != 0;
+    const bool dead = (unsigned)s >= 128u;
+    return v_make(dead ? 0ull : (big ? hi1 : lo1), (dead || big) ? 0ull : hi1);
 }
 
 // utils.h:131-141 "shift_right": bits move away from index 0; 0 for s outside [0,127].
 ASM_DEV V128 v_away0(V128 v, int s) {
-    const bool dead = (unsigned)s >= 128u;
-    const bool big = s >= 64;
     const int r = s & 63;
-    const u64 a = big ? v.lo : v.hi;
-    const u64 b = big ? 0ull : v.lo;
-    u64 hi = (a << r) | (r ? (b >> (64 - r)) : 0ull);
-    u64 lo = b << r;
-    return v_make(dead ? 0ull : lo, dead ? 0ull : hi);
+    const u64 hi1 = (v.hi << r) | ((v.lo >> (63 - r)) >> 1);
+    const u64 lo1 = v.lo << r;
+    const bool big = (s & 64) != 0;
+    const bool dead = (unsigned)s >= 128u;
+    return v_make((dead || big) ? 0ull : lo1, dead ? 0ull : (big ? lo1 : hi1));
 }
 
 // utils.h:168-182: index of the lowest set bit, 128 when there is none.
