@@ -235,6 +235,26 @@ def cpu_baseline_and_parity(asm, eng, hb, batch, params, aligners, sample, d_pen
             want[a] = orc.greedy(sub, params.k, params.x, params.o, params.e, mode=1)
         per[asm.ALIGNER_NAMES[a]] = s / max(time.process_time() - t1, 1e-9)
     cpu_s = time.process_time() - t0
+    # where the real reference travelled with the repo (oracle/_ref, built in the authoring container from
+    # /root/reference; NW's parasail is absent there), time ITS LEAP and Greedy on the same sample, same single thread
+    ref_part = None
+    try:
+        if oracle_binding.have_reference():
+            ref = oracle_binding.load_reference()
+            t1 = time.process_time()
+            r_leap = ref.leap(sub, params.k, params.x, params.o, params.e, full=True)  # incl. backtrack + get_CIGAR
+            t2 = time.process_time()
+            r_greedy = ref.greedy(sub, params.k, params.x, params.o, params.e, mode=1)
+            t3 = time.process_time()
+            ref_part = {"leap_pairs_per_s": s / max(t2 - t1, 1e-9), "greedy_pairs_per_s": s / max(t3 - t2, 1e-9),
+                        "what": "reference sources compiled in place (oracle/_ref), calls as benchmark_utils.h:156-201",
+                        "gpu_equals_reference_pct": {
+                            "leap": 100.0 * float((eng.to_host(d_pen[asm.LEAP], batch.n)[:s] == r_leap).mean())
+                            if asm.LEAP in d_pen else None,
+                            "greedy": 100.0 * float((eng.to_host(d_pen[asm.GREEDY], batch.n)[:s] == r_greedy).mean())
+                            if asm.GREEDY in d_pen else None}}
+    except Exception as exc:  # a checker that cannot load is not a bench failure
+        ref_part = {"error": repr(exc)}
     exact = {}
     for a in aligners:
         got = eng.to_host(d_pen[a], batch.n)[:s]
@@ -248,6 +268,7 @@ def cpu_baseline_and_parity(asm, eng, hb, batch, params, aligners, sample, d_pen
             "sample": f"first {s} pairs of the same seeded batch, oracle/libasm_oracle.so, 1 thread, "
                       f"{cpu_s:.1f} s CPU; per aligner pairs/s: " + ", ".join(f"{k} {v:.3g}" for k, v in per.items()),
             "host_cpus": os.cpu_count(),
+            "reference_parts": ref_part,
         },
         "bit_exact_pct_vs_oracle": dict(exact, sample=s),
     }

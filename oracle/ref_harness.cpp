@@ -85,8 +85,9 @@ int ref_greedy_batch(int64_t n, const char* reads, const uint32_t* read_off, con
     return 0;
 }
 
-int ref_leap_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
-                   const uint32_t* ref_off, int k, int x, int o, int e, int32_t* eds, uint8_t* pass) {
+// full = 1 additionally runs backtrack() and get_CIGAR() as the harness's timed region does (benchmark_utils.h:170-174)
+int ref_leap_batch_ex(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
+                      const uint32_t* ref_off, int k, int x, int o, int e, int32_t* eds, uint8_t* pass, int full) {
     LV* lv = new LV;
     lv->init(k, 200, ED_GLOBAL, x, o, e);
     std::string s1, s2;
@@ -101,11 +102,21 @@ int ref_leap_batch(int64_t n, const char* reads, const uint32_t* read_off, const
         lv->reset();
         lv->run();
         bool ok = lv->check_pass();
+        if (full && ok) {
+            lv->backtrack();
+            std::string c = lv->get_CIGAR();
+            (void)c;
+        }
         eds[i] = ok ? lv->get_ED() : -1;
         if (pass) pass[i] = ok ? 1 : 0;
     }
     delete lv;
     return 0;
+}
+
+int ref_leap_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
+                   const uint32_t* ref_off, int k, int x, int o, int e, int32_t* eds, uint8_t* pass) {
+    return ref_leap_batch_ex(n, reads, read_off, refs, ref_off, k, x, o, e, eds, pass, 0);
 }
 
 // In-place conversion of one 128-byte buffer (buffer is permuted, as in the reference).

@@ -123,6 +123,7 @@ class Reference:
         b5 = [_i64, _vp, _vp, _vp, _vp]
         lib.ref_greedy_batch.argtypes = b5 + [_i] * 4 + [ctypes.c_double] * 3 + [_i, _vp, _vp, _i, _vp]
         lib.ref_leap_batch.argtypes = b5 + [_i] * 4 + [_vp, _vp]
+        lib.ref_leap_batch_ex.argtypes = b5 + [_i] * 4 + [_vp, _vp, _i]
         lib.ref_convert2bit1.argtypes = [_vp, _vp, _vp]
 
     def greedy(self, hb, k=3, x=1, o=1, e=1, probs=DEFAULT_PROBS, mode=1, cigars=False, views=False):
@@ -141,10 +142,11 @@ class Reference:
             out.append(vw[:hb.n * 256].reshape(hb.n, 2, 128))
         return out[0] if len(out) == 1 else tuple(out)
 
-    def leap(self, hb, k=3, x=1, o=1, e=1):
+    def leap(self, hb, k=3, x=1, o=1, e=1, full=False):
+        """full=True also runs backtrack() + get_CIGAR(), as the harness's timed LEAP region does."""
         keep, args = _batch_args(hb)
         eds = np.zeros(hb.n, np.int32)
-        assert self.lib.ref_leap_batch(*args, k, x, o, e, eds.ctypes.data, None) == 0
+        assert self.lib.ref_leap_batch_ex(*args, k, x, o, e, eds.ctypes.data, None, 1 if full else 0) == 0
         return eds
 
     def convert2bit1(self, buf128):
