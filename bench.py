@@ -246,13 +246,16 @@ def cpu_baseline_and_parity(asm, eng, hb, batch, params, aligners, sample, d_pen
             t2 = time.process_time()
             r_greedy = ref.greedy(sub, params.k, params.x, params.o, params.e, mode=1)
             t3 = time.process_time()
+            m_s, n_s = sub.lengths()
+            defined = np.abs(np.minimum(n_s, 128) - np.minimum(m_s, 128)) <= params.k  # else undefined in the reference
             ref_part = {"leap_pairs_per_s": s / max(t2 - t1, 1e-9), "greedy_pairs_per_s": s / max(t3 - t2, 1e-9),
                         "what": "reference sources compiled in place (oracle/_ref), calls as benchmark_utils.h:156-201",
                         "gpu_equals_reference_pct": {
                             "leap": 100.0 * float((eng.to_host(d_pen[asm.LEAP], batch.n)[:s] == r_leap).mean())
                             if asm.LEAP in d_pen else None,
-                            "greedy": 100.0 * float((eng.to_host(d_pen[asm.GREEDY], batch.n)[:s] == r_greedy).mean())
-                            if asm.GREEDY in d_pen else None}}
+                            "greedy": 100.0 * float((eng.to_host(d_pen[asm.GREEDY], batch.n)[:s] == r_greedy)[defined].mean())
+                            if asm.GREEDY in d_pen else None,
+                            "greedy_pairs_undefined_in_reference": int((~defined).sum())}}
     except Exception as exc:  # a checker that cannot load is not a bench failure
         ref_part = {"error": repr(exc)}
     exact = {}
