@@ -340,3 +340,27 @@ def test_pack_maps_every_non_base_byte_to_code_00(asm, engine, oracle):
     for mode in (asm.GREEDY_CLEAN, asm.GREEDY_SEQUENTIAL):
         got = engine.align(engine.upload(hb, mode), asm.GREEDY, asm.Params.default(k=3))
         _check("greedy on dirty alphabet", got, oracle.greedy(hb, k=3, mode=mode), hb)
+
+
+def test_gpu_against_the_real_reference(asm, engine):
+    """Where the compiled reference travelled with the repo (oracle/_ref), compare the HIP path with IT directly —
+    Greedy cost + CIGAR in both buffer modes and LEAP's get_ED — on the pairs the reference defines."""
+    from tests import oracle_binding
+    from tests.util import greedy_defined, leap_defined
+
+    if not oracle_binding.have_reference():
+        pytest.skip("oracle/_ref/libasm_ref.so not present")
+    ref = oracle_binding.load_reference()
+    for wl, n, k in (("C2", 20000, 3), ("C5", 6000, 3), ("C3", 1500, 30)):
+        cfg, _, _ = asm.workload(wl)
+        hb = asm.generate_pairs(cfg, 1234, n)
+        params = asm.Params.default(k=k)
+        gd, ld = greedy_defined(hb, k), leap_defined(hb)
+        for mode in (asm.GREEDY_SEQUENTIAL, asm.GREEDY_CLEAN):
+            batch = engine.upload(hb, mode)
+            cost, cig, _ = engine.greedy_with_cigar(batch, params, cap=96)
+            rcost, rcig = ref.greedy(hb, k=k, mode=mode, cigars=True)
+            assert np.array_equal(cost[gd], rcost[gd]), (wl, mode)
+            assert all(a == b for a, b, d in zip(cig, rcig, gd) if d), (wl, mode, "CIGAR")
+        leap = engine.align(batch, asm.LEAP, params)
+        assert np.array_equal(leap[ld], ref.leap(hb, k=k)[ld]), wl
