@@ -1,4 +1,4 @@
-"""Scratch: per-kernel timing at C2 (1e6 pairs) — used during development, not the driver's bench.py."""
+"""Per-kernel timing for one workload (development tool; run on the GPU box as PYTHONPATH=. python tools/bench_quick.py C2 1e6)."""
 import sys, time
 import numpy as np
 import approximate_string_matching_amd as m
