@@ -34,10 +34,7 @@ struct asm_handle {
     bool bucketing = true;                /* group mixed-length batches by width class (ASM_BUCKET=0 disables) */
     bool wave_kernels = true;             /* wave-per-pair kernels for 6 <= k <= 31 (ASM_WAVE=0: workgroup-per-pair LDS kernels) */
     bool nw_banded = true;                /* banded bit-parallel NW with in-kernel full-height recompute (ASM_NW_BANDED=0) */
-    unsigned long long* d_work = nullptr; /* work-queue heads for the persistent kernels */
-    unsigned work_slot = 0;
 };
-#define ASM_WORK_SLOTS 64
 
 /* One width class of a batch: pairs whose longer string needs `w4` granules of 128 positions. */
 struct asm_bucket {
@@ -212,7 +209,6 @@ int asm_create(asm_handle** out, int device) {
     hipDeviceProp_t prop;
     HIPCHK(h, hipGetDeviceProperties(&prop, device));
     h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    HIPCHK(h, hipMalloc((void**)&h->d_work, sizeof(unsigned long long) * ASM_WORK_SLOTS));
     const char* env = getenv("ASM_PERSIST");
     h->persist = !(env && env[0] == '0');
     if ((env = getenv("ASM_PERSIST_LEAP"))) h->persist_leap = env[0] != '0';
@@ -234,7 +230,6 @@ int asm_destroy(asm_handle* h) {
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-    (void)hipFree(h->d_work);
     delete h;
     return ASM_OK;
 }

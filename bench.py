@@ -235,6 +235,23 @@ def cpu_baseline_and_parity(asm, eng, hb, batch, params, aligners, sample, d_pen
             want[a] = orc.greedy(sub, params.k, params.x, params.o, params.e, mode=1)
         per[asm.ALIGNER_NAMES[a]] = s / max(time.process_time() - t1, 1e-9)
     cpu_s = time.process_time() - t0
+    # the same port on every host core (OpenMP over pairs), whole batch, wall clock
+    all_cores = None
+    try:
+        cores = len(os.sched_getaffinity(0))
+        orc.set_threads(cores)
+        w0 = time.perf_counter()
+        for a in aligners:
+            if a == asm.NW:
+                orc.nw(hb, params.x, params.o, params.e)
+            elif a == asm.LEAP:
+                orc.leap(hb, params.k, params.x, params.o, params.e)
+            else:
+                orc.greedy(hb, params.k, params.x, params.o, params.e, mode=1)
+        all_cores = {"cores": cores, "value": hb.n / (time.perf_counter() - w0), "sample": f"all {hb.n} pairs, wall clock"}
+        orc.set_threads(1)
+    except Exception as exc:
+        all_cores = {"error": repr(exc)}
     # where the real reference travelled with the repo (oracle/_ref, built in the authoring container from
     # /root/reference; NW's parasail is absent there), time ITS LEAP and Greedy on the same sample, same single thread
     ref_part = None
@@ -271,6 +288,7 @@ def cpu_baseline_and_parity(asm, eng, hb, batch, params, aligners, sample, d_pen
             "sample": f"first {s} pairs of the same seeded batch, oracle/libasm_oracle.so, 1 thread, "
                       f"{cpu_s:.1f} s CPU; per aligner pairs/s: " + ", ".join(f"{k} {v:.3g}" for k, v in per.items()),
             "host_cpus": os.cpu_count(),
+            "all_cores": all_cores,
             "reference_parts": ref_part,
         },
         "bit_exact_pct_vs_oracle": dict(exact, sample=s),
