@@ -364,3 +364,20 @@ def test_gpu_against_the_real_reference(asm, engine):
             assert all(a == b for a, b, d in zip(cig, rcig, gd) if d), (wl, mode, "CIGAR")
         leap = engine.align(batch, asm.LEAP, params)
         assert np.array_equal(leap[ld], ref.leap(hb, k=k)[ld]), wl
+
+
+def test_pymatch_named_classes(asm, oracle):
+    """pymatch-style call shape (two strings -> editDistance()) with the C++ harness's numbers."""
+    from approximate_string_matching_amd import pymatch_like as pm
+    from tests.util import KNOWN_PAIRS
+
+    a, b = KNOWN_PAIRS["KA-0"]
+    assert pm.NeedlemanWunsch(a, b).editDistance() == 5
+    assert pm.LEAP(a, b, 3, 200).editDistance() == 5
+    assert pm.GASMA(a, b, 3).editDistance() == 6
+    a5, b5 = KNOWN_PAIRS["KA-5"]
+    assert (pm.NeedlemanWunsch(a5, b5).editDistance(), pm.LEAP(a5, b5, 2, 10).editDistance()) == (3, 2)
+    cfg, _, _ = asm.workload("C1")
+    hb = asm.generate_pairs(cfg, 0, 500)
+    pairs = [hb.pair(i) for i in range(hb.n)]
+    assert np.array_equal(pm.batch_edit_distances(pm.GASMA, pairs, k=3), oracle.greedy(hb, k=3, mode=1))
