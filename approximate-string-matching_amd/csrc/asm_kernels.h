@@ -72,10 +72,7 @@ ASM_DEV void pack_convert(const uint32_t* sb, uint32_t b0, int len, int w4, int 
                     }
 #pragma unroll
                     for (int q = 0; q < 8; q++) {
-                        uint32_t ch = __builtin_amdgcn_alignbit(d[q + 1], d[q], sh);
-                        const int rem = len - (cbase + 4 * q);
-                        const uint32_t vm = rem >= 4 ? ~0u : (rem <= 0 ? 0u : (0xffffffffu >> (32 - 8 * rem)));
-                        ch &= vm;
+                        const uint32_t ch = __builtin_amdgcn_alignbit(d[q + 1], d[q], sh);
                         // Four characters at once.  Bits 1-2 of 'A','C','T','G' are 0,1,2,3: use them as a v_perm_b32
                         // selector into the table "ACTG" to get the one base each byte could be, and accept the byte
                         // only if it IS that base (exactly 'C','G','T' set plane bits; any other byte, NUL included,
@@ -88,6 +85,11 @@ ASM_DEV void pack_convert(const uint32_t* sb, uint32_t b0, int len, int w4, int 
                         q0[w] |= ((f0 * 0x00204081u) >> 28) << (4 * q);
                         q1[w] |= ((f1 * 0x00204081u) >> 28) << (4 * q);
                     }
+                    // characters beyond the string's end (the next pair's bytes in the staging buffer) are dropped here,
+                    // once per 32 positions, instead of being masked out of every dword
+                    const int keep = len - cbase; /* > 0 */
+                    const uint32_t km = keep >= 32 ? ~0u : ((1u << keep) - 1u);
+                    q0[w] &= km, q1[w] &= km;
                 }
             }
             uint4 v0 = make_uint4(q0[0], q0[1], q0[2], q0[3]);
