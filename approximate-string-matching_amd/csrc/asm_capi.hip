@@ -321,9 +321,15 @@ static hipError_t launch_pack(asm_handle* h, const asm_batch* b, const uint4* ta
     const dim3 grid((unsigned)((b->n + ASM_BLOCK - 1) / ASM_BLOCK)), block(ASM_BLOCK);
     int wmax = 1;
     for (int q = 0; q < pb.nb; q++) wmax = pb.w4[q] > wmax ? pb.w4[q] : wmax;
-#define PACK_LAUNCH(W)                                                                                            \
-    hipLaunchKernelGGL(pack_kernel<W>, grid, block, 0, h->stream, b->d_reads, b->d_read_off, b->d_refs, b->d_ref_off, \
-                       tails, planes, lens, (long)b->n, pb, pos)
+    // LDS staging: room for 256 strings of the batch's longest length (+ alignment slack), at least one string
+    size_t stage = (size_t)ASM_BLOCK * (size_t)(b->maxlen + 4) + 64;
+    stage = (stage + 1023) & ~(size_t)1023;
+    if (stage > PACK_SB) stage = PACK_SB;
+    if (stage < 2048) stage = 2048;
+    const size_t lds = stage + 64; /* + the over-read slack of pack_convert */
+#define PACK_LAUNCH(W)                                                                                               \
+    hipLaunchKernelGGL(pack_kernel<W>, grid, block, lds, h->stream, b->d_reads, b->d_read_off, b->d_refs, b->d_ref_off, \
+                       tails, planes, lens, (long)b->n, pb, pos, (uint32_t)stage)
     switch (wmax) {
         case 1: PACK_LAUNCH(1); break;
         case 2: PACK_LAUNCH(2); break;

@@ -115,8 +115,11 @@ __global__ __launch_bounds__(ASM_BLOCK) void pack_kernel(const char* __restrict_
                                                          const uint4* __restrict__ tails, /* [4][n] or null */
                                                          uint4* __restrict__ planes, uint32_t* __restrict__ lens,
                                                          long n, PackBuckets pb,
-                                                         const uint32_t* __restrict__ pos /* pair -> slot, or null */) {
-    __shared__ uint4 s_buf[PACK_SB / 16 + 4];
+                                                         const uint32_t* __restrict__ pos /* pair -> slot, or null */,
+                                                         uint32_t stage_bytes /* dynamic LDS staging size, <= PACK_SB */) {
+    // staging buffer sized by the host from the batch's longest string: short reads leave room for more resident
+    // workgroups per CU (5 at 100 bp instead of 3), which is what hides the HBM latency of the staging loads
+    extern __shared__ uint4 s_buf[];
     __shared__ uint32_t s_off[2][ASM_BLOCK + 1];
     const int t = threadIdx.x;
     const long p0 = (long)blockIdx.x * ASM_BLOCK;
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void pack_kernel(const char* __restrict_
     const uint32_t bytesA = s_off[0][ASM_BLOCK] - baseA, bytesB = s_off[1][ASM_BLOCK] - baseB;
     if (t < np) lens[slot] = (oA1 - oA0) | ((oB1 - oB0) << 16);
 
-    if (bytesA <= (uint32_t)PACK_SB && bytesB <= (uint32_t)PACK_SB) {
+    if (bytesA <= stage_bytes && bytesB <= stage_bytes) {
         // Fast path (every string of the block fits the buffer): the refs' bytes are fetched into registers while the
         // reads are being converted, so their HBM latency hides behind the SWAR work.
         const int nvA = (int)((bytesA + 15u) >> 4), nvB = (int)((bytesB + 15u) >> 4);
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void pack_kernel(const char* __restrict_
         while (ps < np) { /* uniform across the workgroup */
             __syncthreads();
             const uint32_t base = s_off[s][ps] & ~15u;
-            const int fits = (t >= ps && t < np && (o1 - base) <= (uint32_t)PACK_SB) ? 1 : 0;
+            const int fits = (t >= ps && t < np && (o1 - base) <= stage_bytes) ? 1 : 0;
             const int pe = ps + __syncthreads_count(fits); /* offsets are monotone: the fitting pairs are [ps, pe) */
             const uint32_t hi = s_off[s][pe];
             const int nvec = (int)((hi - base + 15u) >> 4);
