@@ -327,9 +327,13 @@ static hipError_t launch_pack(asm_handle* h, const asm_batch* b, const uint4* ta
     if (stage > PACK_SB) stage = PACK_SB;
     if (stage < 2048) stage = 2048;
     const size_t lds = stage + 64; /* + the over-read slack of pack_convert */
-#define PACK_LAUNCH(W)                                                                                               \
-    hipLaunchKernelGGL(pack_kernel<W>, grid, block, lds, h->stream, b->d_reads, b->d_read_off, b->d_refs, b->d_ref_off, \
-                       tails, planes, lens, (long)b->n, pb, pos, (uint32_t)stage)
+#define PACK_LAUNCH(W)                                                                                                    \
+    if (stage <= 7 * ASM_BLOCK * 16)                                                                                      \
+        hipLaunchKernelGGL((pack_kernel<W, 7>), grid, block, lds, h->stream, b->d_reads, b->d_read_off, b->d_refs,        \
+                           b->d_ref_off, tails, planes, lens, (long)b->n, pb, pos, (uint32_t)stage);                      \
+    else                                                                                                                  \
+        hipLaunchKernelGGL((pack_kernel<W, 12>), grid, block, lds, h->stream, b->d_reads, b->d_read_off, b->d_refs,       \
+                           b->d_ref_off, tails, planes, lens, (long)b->n, pb, pos, (uint32_t)stage)
     switch (wmax) {
         case 1: PACK_LAUNCH(1); break;
         case 2: PACK_LAUNCH(2); break;

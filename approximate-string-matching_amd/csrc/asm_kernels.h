@@ -105,9 +105,8 @@ ASM_DEV void pack_convert(const uint32_t* sb, uint32_t b0, int len, int w4, int 
     }
 }
 
-#define PACK_NV (PACK_SB / 16 / ASM_BLOCK) /* staging vectors per thread when a string's bytes fit the buffer */
 
-template <int W4>
+template <int W4, int NV> /* NV = staging vectors (16 B) per thread the fast path may hold in registers */
 __global__ __launch_bounds__(ASM_BLOCK) void pack_kernel(const char* __restrict__ reads,
                                                          const uint32_t* __restrict__ read_off,
                                                          const char* __restrict__ refs,
@@ -145,7 +144,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void pack_kernel(const char* __restrict_
     const uint32_t bytesA = s_off[0][ASM_BLOCK] - baseA, bytesB = s_off[1][ASM_BLOCK] - baseB;
     if (t < np) lens[slot] = (oA1 - oA0) | ((oB1 - oB0) << 16);
 
-    if (bytesA <= stage_bytes && bytesB <= stage_bytes) {
+    if (bytesA <= stage_bytes && bytesB <= stage_bytes && bytesB <= (uint32_t)(NV * ASM_BLOCK * 16)) {
         // Fast path (every string of the block fits the buffer): the refs' bytes are fetched into registers while the
         // reads are being converted, so their HBM latency hides behind the SWAR work.
         const int nvA = (int)((bytesA + 15u) >> 4), nvB = (int)((bytesB + 15u) >> 4);
@@ -155,9 +154,9 @@ __global__ __launch_bounds__(ASM_BLOCK) void pack_kernel(const char* __restrict_
             const int a = 4 * v;
             s_buf[(a ^ (((a >> 5) & 7) << 2)) >> 2] = srcA[v];
         }
-        uint4 rb[PACK_NV];
+        uint4 rb[NV];
 #pragma unroll
-        for (int q = 0; q < PACK_NV; q++) {
+        for (int q = 0; q < NV; q++) {
             const int v = t + q * ASM_BLOCK;
             rb[q] = v < nvB ? srcB[v] : make_uint4(0u, 0u, 0u, 0u);
         }
@@ -165,7 +164,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void pack_kernel(const char* __restrict_
         if (t < np) pack_convert<W4>(sb, oA0 - baseA, (int)(oA1 - oA0), w4, 0, tails, n, p0 + t, bplanes, bn, local);
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < PACK_NV; q++) {
+        for (int q = 0; q < NV; q++) {
             const int v = t + q * ASM_BLOCK;
             if (v < nvB) {
                 const int a = 4 * v;
