@@ -132,6 +132,7 @@ static hipError_t launch_leap_unit_w(asm_handle* h, const asm_bucket& b, OutMap 
 template <int K>
 static hipError_t launch_leap_unit(asm_handle* h, const asm_bucket& b, OutMap out, const int32_t* hint) {
     if (b.maxlen <= 128) return launch_leap_unit_w<K, 2>(h, b, out, hint);
+    if (b.maxlen <= 192) return launch_leap_unit_w<K, 3>(h, b, out, hint);
     if (b.maxlen <= 256) return launch_leap_unit_w<K, 4>(h, b, out, hint);
     return launch_leap_unit_w<K, 6>(h, b, out, hint);
 }
@@ -805,12 +806,11 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
         } else if (unit && p->k <= ASM_WAVE_MAX_K && h->wave_kernels) {
 #define LEAP_WAVE(W) \
     launch_wave_per_pair(h->stream, leap_wave_kernel<W>, b.n, h->num_cus, planes, lens, (long)b.n, b.w4, (int)p->k, out)
-            switch (b.w4) {
-                case 1: LEAP_WAVE(2); break;
-                case 2: LEAP_WAVE(4); break;
-                case 3: LEAP_WAVE(6); break;
-                default: LEAP_WAVE(8); break;
-            }
+            if (b.maxlen <= 128) LEAP_WAVE(2);
+            else if (b.maxlen <= 192) LEAP_WAVE(3);
+            else if (b.maxlen <= 256) LEAP_WAVE(4);
+            else if (b.maxlen <= 384) LEAP_WAVE(6);
+            else LEAP_WAVE(8);
 #undef LEAP_WAVE
         } else {
             launch_leap_wide(h->stream, planes, lens, b.n, b.w4, p->k, p->x, p->o, p->e, out);

@@ -638,21 +638,20 @@ template <int W64>
 ASM_DEV void load_planes(const uint4* __restrict__ planes, long n, int w4, long i, VW<W64>& A0, VW<W64>& A1,
                          VW<W64>& B0, VW<W64>& B1) {
 #pragma unroll
-    for (int g = 0; g < W64 / 2; g++) {
-        if (g >= w4) { /* vector wider than the batch's granule count: upper words are empty */
-            A0.w[2 * g] = A0.w[2 * g + 1] = A1.w[2 * g] = A1.w[2 * g + 1] = 0ull;
-            B0.w[2 * g] = B0.w[2 * g + 1] = B1.w[2 * g] = B1.w[2 * g + 1] = 0ull;
-            continue;
+    for (int g = 0; g < (W64 + 1) / 2; g++) { /* an odd W64 takes only the low half of its last granule */
+        uint4 qa0 = make_uint4(0u, 0u, 0u, 0u), qa1 = qa0, qb0 = qa0, qb1 = qa0;
+        if (g < w4) { /* a vector wider than the batch's granule count has empty upper words */
+            qa0 = planes[((long)0 * w4 + g) * n + i];
+            qa1 = planes[((long)1 * w4 + g) * n + i];
+            qb0 = planes[((long)2 * w4 + g) * n + i];
+            qb1 = planes[((long)3 * w4 + g) * n + i];
         }
-        uint4 q;
-        q = planes[((long)0 * w4 + g) * n + i];
-        A0.w[2 * g] = (u64)q.x | ((u64)q.y << 32), A0.w[2 * g + 1] = (u64)q.z | ((u64)q.w << 32);
-        q = planes[((long)1 * w4 + g) * n + i];
-        A1.w[2 * g] = (u64)q.x | ((u64)q.y << 32), A1.w[2 * g + 1] = (u64)q.z | ((u64)q.w << 32);
-        q = planes[((long)2 * w4 + g) * n + i];
-        B0.w[2 * g] = (u64)q.x | ((u64)q.y << 32), B0.w[2 * g + 1] = (u64)q.z | ((u64)q.w << 32);
-        q = planes[((long)3 * w4 + g) * n + i];
-        B1.w[2 * g] = (u64)q.x | ((u64)q.y << 32), B1.w[2 * g + 1] = (u64)q.z | ((u64)q.w << 32);
+        A0.w[2 * g] = (u64)qa0.x | ((u64)qa0.y << 32), A1.w[2 * g] = (u64)qa1.x | ((u64)qa1.y << 32);
+        B0.w[2 * g] = (u64)qb0.x | ((u64)qb0.y << 32), B1.w[2 * g] = (u64)qb1.x | ((u64)qb1.y << 32);
+        if (2 * g + 1 < W64) {
+            A0.w[2 * g + 1] = (u64)qa0.z | ((u64)qa0.w << 32), A1.w[2 * g + 1] = (u64)qa1.z | ((u64)qa1.w << 32);
+            B0.w[2 * g + 1] = (u64)qb0.z | ((u64)qb0.w << 32), B1.w[2 * g + 1] = (u64)qb1.z | ((u64)qb1.w << 32);
+        }
     }
 }
 
