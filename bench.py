@@ -39,6 +39,23 @@ def pmc_traffic(kernel, pairs):
         return None
 
 
+def valu_roofline(kernel, pairs, launch_ms):
+    """The roofline that actually bounds these kernels: VALU issue.  Instructions per launch come from the
+    SQ_INSTS_VALU counter (profiles/r01_pmc_valu.json, collected with tools/pmc_sq.sh); the ceiling is what the SIMDs can
+    issue for this instruction mix (measured ~4.3 cycles per wave-instruction, tools/ubench/valu_rates)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_valu.json")
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        insts = d["kernels"][kernel]["insts_valu"] * pairs / d["pairs"]
+        peak = d["simd_count"] * d["nominal_clock_hz"] / d["cycles_per_inst_mix"]
+        achieved = insts / (launch_ms * 1e-3)
+        return {"bound": "valu-issue", "insts_per_launch": insts, "achieved": achieved, "peak": peak,
+                "unit": "wave-instructions/s", "frac": achieved / peak}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def algorithmic_bytes(m, n, aligners=1):
     """2-bit packed inputs read once + one int32 penalty per aligner, per pair."""
     return (np.ceil(2 * m / 8) + np.ceil(2 * n / 8) + 4 * aligners).sum()
