@@ -218,7 +218,8 @@ def main():
                 "traffic": pmc_traffic(dom, n),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": kernel_ms[dom],
-                "note": "integer-VALU-bound path (SURVEY.md F7): see DESIGN.md §5 for the VALU-side ceiling",
+                "note": "integer-VALU-bound path (SURVEY.md F7): the binding roofline is in `valu`",
+                "valu": valu_roofline(dom, n, kernel_ms[dom]),
             },
         }
         if world == 1 and not args.no_cpu_baseline:
