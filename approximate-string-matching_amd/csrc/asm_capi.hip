@@ -129,6 +129,28 @@ static hipError_t launch_leap_unit_w(asm_handle* h, const asm_bucket& b, OutMap 
     return hipGetLastError();
 }
 
+template <int K, int W64>
+static hipError_t launch_leap_general_w(asm_handle* h, const asm_bucket& b, const asm_params* p, OutMap out) {
+    const dim3 grid((unsigned)((b.n + LEAP_GEN_THREADS - 1) / LEAP_GEN_THREADS)), block(LEAP_GEN_THREADS);
+    const int pmax = p->x > p->o ? p->x : p->o; /* o >= e is checked */
+    if (pmax < 4)
+        hipLaunchKernelGGL((leap_general_kernel<K, W64, 4>), grid, block, 0, h->stream, b.planes, b.lens, (long)b.n, b.w4,
+                           (int)p->x, (int)p->o, (int)p->e, out);
+    else if (pmax < 8)
+        hipLaunchKernelGGL((leap_general_kernel<K, W64, 8>), grid, block, 0, h->stream, b.planes, b.lens, (long)b.n, b.w4,
+                           (int)p->x, (int)p->o, (int)p->e, out);
+    else
+        hipLaunchKernelGGL((leap_general_kernel<K, W64, 16>), grid, block, 0, h->stream, b.planes, b.lens, (long)b.n, b.w4,
+                           (int)p->x, (int)p->o, (int)p->e, out);
+    return hipGetLastError();
+}
+
+template <int K>
+static hipError_t launch_leap_general(asm_handle* h, const asm_bucket& b, const asm_params* p, OutMap out) {
+    if (b.maxlen <= 128) return launch_leap_general_w<K, 2>(h, b, p, out);
+    return launch_leap_general_w<K, 4>(h, b, p, out);
+}
+
 template <int K>
 static hipError_t launch_leap_unit(asm_handle* h, const asm_bucket& b, OutMap out, const int32_t* hint) {
     if (b.maxlen <= 128) return launch_leap_unit_w<K, 2>(h, b, out, hint);
@@ -802,6 +824,13 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
                 case 3: HIPCHK(h, launch_leap_unit<3>(h, b, out, hint)); break;
                 case 4: HIPCHK(h, launch_leap_unit<4>(h, b, out, hint)); break;
                 default: HIPCHK(h, launch_leap_unit<5>(h, b, out, hint)); break;
+            }
+        } else if (!unit && p->k >= 1 && p->k <= 3 && b.maxlen <= 256 && h->wave_kernels) {
+            /* general penalties, narrow band: thread per pair with an LDS generation ring */
+            switch (p->k) {
+                case 1: HIPCHK(h, launch_leap_general<1>(h, b, p, out)); break;
+                case 2: HIPCHK(h, launch_leap_general<2>(h, b, p, out)); break;
+                default: HIPCHK(h, launch_leap_general<3>(h, b, p, out)); break;
             }
         } else if (unit && p->k <= ASM_WAVE_MAX_K && h->wave_kernels) {
 #define LEAP_WAVE(W) \

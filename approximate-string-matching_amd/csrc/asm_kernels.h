@@ -810,6 +810,87 @@ __global__ __launch_bounds__(ASM_BLOCK) void leap_unit_hint_kernel(const uint4* 
     }
 }
 
+// --------------------------------------------------------------------------------------------------------
+// LEAP with general penalties (x, o, ext), narrow band, one thread per pair.  The recurrence reads generations e-o,
+// e-ext and e-x (LV_BAG.cpp:166-187), so a ring of G = 2^g > max(x, o, ext) generations is kept — per thread, as int16
+// (positions <= 512), in LDS laid out [value][slot][lane][thread]: thread-private columns, so no barriers and no bank
+// conflicts.  Every slot read in generation e was written earlier for THIS pair (the e >= penalty guards of the
+// reference), so the ring needs no clearing between pairs.
+// --------------------------------------------------------------------------------------------------------
+#define LEAP_GEN_THREADS 128
+template <int K, int W64, int G>
+__global__ __launch_bounds__(LEAP_GEN_THREADS) void leap_general_kernel(const uint4* __restrict__ planes,
+                                                                        const uint32_t* __restrict__ lens, long n, int w4,
+                                                                        int x, int o, int ext, OutMap out) {
+    constexpr int NL = 2 * K + 1;
+    __shared__ short s_en[G][NL][LEAP_GEN_THREADS], s_ip[G][NL][LEAP_GEN_THREADS], s_dp[G][NL][LEAP_GEN_THREADS];
+    const int t = threadIdx.x;
+    const long i = (long)blockIdx.x * LEAP_GEN_THREADS + t;
+    if (i >= n) return;
+    const uint32_t ln = lens[i];
+    const int m = (int)(ln & 0xffffu), nn = (int)(ln >> 16);
+    const int len = m > nn ? m : nn; /* benchmark_utils.h:162 */
+    VW<W64> A0, A1, B0, B1;
+    load_planes<W64>(planes, n, w4, i, A0, A1, B0, B1);
+    const VW<W64> VA = vw_low_ones<W64>(m), VB = vw_low_ones<W64>(nn);
+    VW<W64> mask[NL];
+#pragma unroll
+    for (int j = 0; j < NL; j++) mask[j] = leap_lane_mask<W64>(A0, A1, B0, B1, VA, VB, j - K);
+
+    int result = -1;
+    // e = 0: only the main diagonal is live (LV_BAG.cpp:102-104,131-147)
+#pragma unroll
+    for (int j = 0; j < NL; j++) s_en[0][j][t] = -2, s_ip[0][j][t] = -2, s_dp[0][j][t] = -2;
+    {
+        int e0 = vw_next_one<W64>(mask[K], 0);
+        e0 = e0 > len ? len : e0;
+        s_en[0][K][t] = (short)e0;
+        if (e0 == len) result = 0;
+    }
+    for (int e = 1; e <= ASM_LEAP_AF_THRESHOLD && result < 0; e++) {
+        const int so = (e - o) & (G - 1), se = (e - ext) & (G - 1), sx = (e - x) & (G - 1), sw = e & (G - 1);
+        const bool has_o = e >= o, has_e = e >= ext, has_x = e >= x;
+        bool pass = false;
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            const int d = j - K;
+            const int top = d >= 0 ? 1 : 0, bot = d <= 0 ? 1 : 0;
+            const int e_up = (j > 0 && has_o) ? (int)s_en[so][j > 0 ? j - 1 : 0][t] : -2;
+            const int i_up = (j > 0 && has_e) ? (int)s_ip[se][j > 0 ? j - 1 : 0][t] : -2;
+            const int e_dn = (j < NL - 1 && has_o) ? (int)s_en[so][j < NL - 1 ? j + 1 : j][t] : -2;
+            const int d_dn = (j < NL - 1 && has_e) ? (int)s_dp[se][j < NL - 1 ? j + 1 : j][t] : -2;
+            const int own = has_x ? (int)s_en[sx][j][t] : -2;
+            int inew = -2, dnew = -2;
+            if (e_up >= 0 && e_up > i_up)
+                inew = e_up + top; /* LV_BAG.cpp:166-167 */
+            else if (i_up >= 0)
+                inew = i_up + top; /* :172-176 */
+            if (e_dn >= 0 && e_dn > d_dn)
+                dnew = e_dn + bot; /* :179-180 */
+            else if (d_dn >= 0)
+                dnew = d_dn + bot; /* :181-182 */
+            int st = own >= 0 ? own + 1 : -2; /* :186-187 */
+            st = inew > st ? inew : st;
+            st = dnew > st ? dnew : st;
+            int enew = -2;
+            if (st >= 0) {
+                const int from = st > len ? len : st;
+                int r = vw_next_one<W64>(mask[j], from); /* count_ID_length, :9-23 */
+                r = r > len ? len : r;
+                enew = st > len ? st : r;
+                if (enew == len) { /* :220-238 */
+                    const int diff = d < 0 ? -d : d;
+                    const int conv = e + (diff ? o + (diff - 1) * ext : 0);
+                    if (conv <= ASM_LEAP_AF_THRESHOLD) pass = true;
+                }
+            }
+            s_en[sw][j][t] = (short)enew, s_ip[sw][j][t] = (short)inew, s_dp[sw][j][t] = (short)dnew;
+        }
+        if (pass) result = e; /* final_ED (LV_BAG.cpp:228,356-358) */
+    }
+    out.put(i, result);
+}
+
 // Persistent, lane-refilling form of leap_unit_kernel<K,W64>: a pair needs final_ED+1 generations (mean ~8, max >30
 // at err 0.10); lanes pull the next pair as soon as theirs passes (see greedy_persist_kernel).
 template <int K, int W64>
