@@ -34,6 +34,9 @@ struct asm_handle {
     bool bucketing = true;                /* group mixed-length batches by width class (ASM_BUCKET=0 disables) */
     bool wave_kernels = true;             /* wave-per-pair kernels for 6 <= k <= 31 (ASM_WAVE=0: workgroup-per-pair LDS kernels) */
     bool nw_banded = true;                /* banded bit-parallel NW with in-kernel full-height recompute (ASM_NW_BANDED=0) */
+    bool nw_wfa = true;                   /* affine NW: banded wavefront first, full matrix for the rest (ASM_NW_WFA=0: full matrix only) */
+    uint32_t* d_todo = nullptr;           /* affine NW: [0] = count, [1..] = bucket slots the wavefront band could not settle */
+    size_t todo_cap = 0;
 };
 
 /* One width class of a batch: pairs whose longer string needs `w4` granules of 128 positions. */
@@ -132,17 +135,32 @@ static hipError_t launch_leap_unit_w(asm_handle* h, const asm_bucket& b, OutMap 
 template <int K, int W64>
 static hipError_t launch_leap_general_w(asm_handle* h, const asm_bucket& b, const asm_params* p, OutMap out) {
     const dim3 grid((unsigned)((b.n + LEAP_GEN_THREADS - 1) / LEAP_GEN_THREADS)), block(LEAP_GEN_THREADS);
-    const int pmax = p->x > p->o ? p->x : p->o; /* o >= e is checked */
-    if (pmax < 4)
-        hipLaunchKernelGGL((leap_general_kernel<K, W64, 4>), grid, block, 0, h->stream, b.planes, b.lens, (long)b.n, b.w4,
-                           (int)p->x, (int)p->o, (int)p->e, out);
-    else if (pmax < 8)
-        hipLaunchKernelGGL((leap_general_kernel<K, W64, 8>), grid, block, 0, h->stream, b.planes, b.lens, (long)b.n, b.w4,
-                           (int)p->x, (int)p->o, (int)p->e, out);
-    else
-        hipLaunchKernelGGL((leap_general_kernel<K, W64, 16>), grid, block, 0, h->stream, b.planes, b.lens, (long)b.n, b.w4,
-                           (int)p->x, (int)p->o, (int)p->e, out);
+    const RingGeometry rg(p->x, p->o, p->e);
+    hipLaunchKernelGGL((leap_general_kernel<K, W64>), grid, block, rg.lds_bytes(2 * K + 1, LEAP_GEN_THREADS), h->stream,
+                       b.planes, b.lens, (long)b.n, b.w4, (int)p->x, (int)p->o, (int)p->e, rg.gm, rg.gi, out);
     return hipGetLastError();
+}
+
+/* Affine NW: banded wavefront pass, then the full-matrix kernel over the pairs the band could not settle. */
+template <int W64, int MAXROWS>
+static int launch_nw_wfa(asm_handle* h, const asm_bucket& b, const asm_params* p, OutMap out) {
+    if (h->todo_cap < (size_t)b.n + 1) {
+        if (h->d_todo) (void)hipFree(h->d_todo);
+        h->d_todo = nullptr, h->todo_cap = 0;
+        HIPCHK(h, hipMalloc((void**)&h->d_todo, sizeof(uint32_t) * ((size_t)b.n + 1)));
+        h->todo_cap = (size_t)b.n + 1;
+    }
+    HIPCHK(h, hipMemsetAsync(h->d_todo, 0, sizeof(uint32_t), h->stream));
+    const RingGeometry rg(p->x, p->o, p->e);
+    const dim3 grid((unsigned)((b.n + LEAP_GEN_THREADS - 1) / LEAP_GEN_THREADS)), block(LEAP_GEN_THREADS);
+    hipLaunchKernelGGL((nw_wfa_kernel<NW_WFA_K, W64>), grid, block, rg.lds_bytes(2 * NW_WFA_K + 1, LEAP_GEN_THREADS), h->stream,
+                       b.planes, b.lens, (long)b.n, b.w4, (int)p->x, (int)p->o, (int)p->e, rg.gm, rg.gi, out, h->d_todo + 1,
+                       h->d_todo);
+    hipLaunchKernelGGL((nw_affine_kernel<W64, MAXROWS>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 0, h->stream, b.planes,
+                       b.lens, (long)b.n, b.w4, (int)p->x, (int)p->o, (int)p->e, out, (const uint32_t*)(h->d_todo + 1),
+                       (const uint32_t*)h->d_todo);
+    HIPCHK(h, hipGetLastError());
+    return ASM_OK;
 }
 
 template <int K>
@@ -240,6 +258,7 @@ int asm_create(asm_handle** out, int device) {
     if ((env = getenv("ASM_BUCKET"))) h->bucketing = env[0] != '0';
     if ((env = getenv("ASM_WAVE"))) h->wave_kernels = env[0] != '0';
     if ((env = getenv("ASM_NW_BANDED"))) h->nw_banded = env[0] != '0';
+    if ((env = getenv("ASM_NW_WFA"))) h->nw_wfa = env[0] != '0';
     if ((env = getenv("ASM_REFILL_GREEDY"))) h->refill_greedy = atoi(env);
     if ((env = getenv("ASM_REFILL_LEAP"))) h->refill_leap = atoi(env);
     *out = h;
@@ -253,6 +272,7 @@ int asm_destroy(asm_handle* h) {
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->d_todo) (void)hipFree(h->d_todo);
     delete h;
     return ASM_OK;
 }
@@ -825,12 +845,15 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
                 case 4: HIPCHK(h, launch_leap_unit<4>(h, b, out, hint)); break;
                 default: HIPCHK(h, launch_leap_unit<5>(h, b, out, hint)); break;
             }
-        } else if (!unit && p->k >= 1 && p->k <= 3 && b.maxlen <= 256 && h->wave_kernels) {
+        } else if (!unit && p->k >= 1 && p->k <= 5 && b.maxlen <= 256 && h->wave_kernels &&
+                   RingGeometry(p->x, p->o, p->e).lds_bytes(2 * p->k + 1, LEAP_GEN_THREADS) <= 64 * 1024) {
             /* general penalties, narrow band: thread per pair with an LDS generation ring */
             switch (p->k) {
                 case 1: HIPCHK(h, launch_leap_general<1>(h, b, p, out)); break;
                 case 2: HIPCHK(h, launch_leap_general<2>(h, b, p, out)); break;
-                default: HIPCHK(h, launch_leap_general<3>(h, b, p, out)); break;
+                case 3: HIPCHK(h, launch_leap_general<3>(h, b, p, out)); break;
+                case 4: HIPCHK(h, launch_leap_general<4>(h, b, p, out)); break;
+                default: HIPCHK(h, launch_leap_general<5>(h, b, p, out)); break;
             }
         } else if (unit && p->k <= ASM_WAVE_MAX_K && h->wave_kernels) {
 #define LEAP_WAVE(W) \
@@ -866,7 +889,13 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
             else
                 hipLaunchKernelGGL((nw_banded_kernel<16, 64>), g, t, 0, h->stream, planes, lens, n, b.w4, out);
         } else {
-            launch_nw_affine(h->stream, planes, lens, b.n, b.w4, b.maxlen, p->x, p->o, p->e, out);
+            const RingGeometry rg(p->x, p->o, p->e);
+            if (h->nw_wfa && b.maxlen <= 256 && rg.lds_bytes(2 * NW_WFA_K + 1, LEAP_GEN_THREADS) <= 64 * 1024) {
+                const int rc = b.maxlen <= 128 ? launch_nw_wfa<2, 128>(h, b, p, out) : launch_nw_wfa<4, 256>(h, b, p, out);
+                if (rc != ASM_OK) return rc;
+            } else {
+                launch_nw_affine(h->stream, planes, lens, b.n, b.w4, b.maxlen, p->x, p->o, p->e, out);
+            }
         }
     }
     HIPCHK(h, hipGetLastError());

@@ -812,20 +812,35 @@ __global__ __launch_bounds__(ASM_BLOCK) void leap_unit_hint_kernel(const uint4* 
 
 // --------------------------------------------------------------------------------------------------------
 // LEAP with general penalties (x, o, ext), narrow band, one thread per pair.  The recurrence reads generations e-o,
-// e-ext and e-x (LV_BAG.cpp:166-187), so a ring of G = 2^g > max(x, o, ext) generations is kept — per thread, as int16
-// (positions <= 512), in LDS laid out [value][slot][lane][thread]: thread-private columns, so no barriers and no bank
-// conflicts.  Every slot read in generation e was written earlier for THIS pair (the e >= penalty guards of the
-// reference), so the ring needs no clearing between pairs.
+// e-x (end) and e-ext (I, D) (LV_BAG.cpp:166-187), so rings of GM = 2^a > max(x, o) generations of `end` and
+// GI = 2^b > ext generations of I and D are kept — per thread, as int16 (positions <= 512), in dynamic LDS laid out
+// [ring][slot][lane][thread]: thread-private columns, so no barriers and no bank conflicts; slot offsets are wave-uniform
+// (scalar).  Every slot read in generation e was written earlier for THIS pair (the e >= penalty guards of the
+// reference), so the rings need no clearing between pairs.
 // --------------------------------------------------------------------------------------------------------
 #define LEAP_GEN_THREADS 128
-template <int K, int W64, int G>
+struct RingGeometry { /* power-of-two ring depths for (x, o, e) and the LDS bytes a block of T threads with NL lanes needs */
+    int gm, gi;
+    __host__ __device__ static int pow2_above(int v) {
+        int g = 2;
+        while (g <= v) g <<= 1;
+        return g;
+    }
+    __host__ RingGeometry(int x, int o, int e) : gm(pow2_above(x > o ? x : o)), gi(pow2_above(e)) {}
+    __host__ size_t lds_bytes(int nl, int threads) const { return (size_t)(gm + 2 * gi) * nl * threads * sizeof(short); }
+};
+
+template <int K, int W64>
 __global__ __launch_bounds__(LEAP_GEN_THREADS) void leap_general_kernel(const uint4* __restrict__ planes,
                                                                         const uint32_t* __restrict__ lens, long n, int w4,
-                                                                        int x, int o, int ext, OutMap out) {
-    constexpr int NL = 2 * K + 1;
-    __shared__ short s_en[G][NL][LEAP_GEN_THREADS], s_ip[G][NL][LEAP_GEN_THREADS], s_dp[G][NL][LEAP_GEN_THREADS];
+                                                                        int x, int o, int ext, int gm, int gi, OutMap out) {
+    constexpr int NL = 2 * K + 1, T = LEAP_GEN_THREADS, SLOT = NL * T;
+    extern __shared__ short s_ring[];
     const int t = threadIdx.x;
-    const long i = (long)blockIdx.x * LEAP_GEN_THREADS + t;
+    short* const r_en = s_ring + t;
+    short* const r_ip = r_en + gm * SLOT;
+    short* const r_dp = r_ip + gi * SLOT;
+    const long i = (long)blockIdx.x * T + t;
     if (i >= n) return;
     const uint32_t ln = lens[i];
     const int m = (int)(ln & 0xffffu), nn = (int)(ln >> 16);
@@ -840,26 +855,32 @@ __global__ __launch_bounds__(LEAP_GEN_THREADS) void leap_general_kernel(const ui
     int result = -1;
     // e = 0: only the main diagonal is live (LV_BAG.cpp:102-104,131-147)
 #pragma unroll
-    for (int j = 0; j < NL; j++) s_en[0][j][t] = -2, s_ip[0][j][t] = -2, s_dp[0][j][t] = -2;
+    for (int j = 0; j < NL; j++) r_en[j * T] = -2, r_ip[j * T] = -2, r_dp[j * T] = -2;
     {
         int e0 = vw_next_one<W64>(mask[K], 0);
         e0 = e0 > len ? len : e0;
-        s_en[0][K][t] = (short)e0;
+        r_en[K * T] = (short)e0;
         if (e0 == len) result = 0;
     }
     for (int e = 1; e <= ASM_LEAP_AF_THRESHOLD && result < 0; e++) {
-        const int so = (e - o) & (G - 1), se = (e - ext) & (G - 1), sx = (e - x) & (G - 1), sw = e & (G - 1);
+        const short* const en_o = r_en + ((e - o) & (gm - 1)) * SLOT;
+        const short* const en_x = r_en + ((e - x) & (gm - 1)) * SLOT;
+        const short* const ip_e = r_ip + ((e - ext) & (gi - 1)) * SLOT;
+        const short* const dp_e = r_dp + ((e - ext) & (gi - 1)) * SLOT;
+        short* const en_w = r_en + (e & (gm - 1)) * SLOT;
+        short* const ip_w = r_ip + (e & (gi - 1)) * SLOT;
+        short* const dp_w = r_dp + (e & (gi - 1)) * SLOT;
         const bool has_o = e >= o, has_e = e >= ext, has_x = e >= x;
         bool pass = false;
 #pragma unroll
         for (int j = 0; j < NL; j++) {
             const int d = j - K;
             const int top = d >= 0 ? 1 : 0, bot = d <= 0 ? 1 : 0;
-            const int e_up = (j > 0 && has_o) ? (int)s_en[so][j > 0 ? j - 1 : 0][t] : -2;
-            const int i_up = (j > 0 && has_e) ? (int)s_ip[se][j > 0 ? j - 1 : 0][t] : -2;
-            const int e_dn = (j < NL - 1 && has_o) ? (int)s_en[so][j < NL - 1 ? j + 1 : j][t] : -2;
-            const int d_dn = (j < NL - 1 && has_e) ? (int)s_dp[se][j < NL - 1 ? j + 1 : j][t] : -2;
-            const int own = has_x ? (int)s_en[sx][j][t] : -2;
+            const int e_up = (j > 0 && has_o) ? (int)en_o[(j > 0 ? j - 1 : 0) * T] : -2;
+            const int i_up = (j > 0 && has_e) ? (int)ip_e[(j > 0 ? j - 1 : 0) * T] : -2;
+            const int e_dn = (j < NL - 1 && has_o) ? (int)en_o[(j < NL - 1 ? j + 1 : j) * T] : -2;
+            const int d_dn = (j < NL - 1 && has_e) ? (int)dp_e[(j < NL - 1 ? j + 1 : j) * T] : -2;
+            const int own = has_x ? (int)en_x[j * T] : -2;
             int inew = -2, dnew = -2;
             if (e_up >= 0 && e_up > i_up)
                 inew = e_up + top; /* LV_BAG.cpp:166-167 */
@@ -884,11 +905,125 @@ __global__ __launch_bounds__(LEAP_GEN_THREADS) void leap_general_kernel(const ui
                     if (conv <= ASM_LEAP_AF_THRESHOLD) pass = true;
                 }
             }
-            s_en[sw][j][t] = (short)enew, s_ip[sw][j][t] = (short)inew, s_dp[sw][j][t] = (short)dnew;
+            en_w[j * T] = (short)enew, ip_w[j * T] = (short)inew, dp_w[j * T] = (short)dnew;
         }
         if (pass) result = e; /* final_ED (LV_BAG.cpp:228,356-358) */
     }
     out.put(i, result);
+}
+
+// --------------------------------------------------------------------------------------------------------
+// NW with affine gaps as a banded wavefront (furthest-reaching offsets per diagonal and score), one thread per pair —
+// the same LDS rings as leap_general_kernel.  Diagonal d = j - i (i: read characters consumed, j: reference characters),
+// lanes d in [-K, K].  M[s][d] = furthest i with cost s ending in a match/mismatch state; I consumes the reference
+// (d-1 -> d, i unchanged), D consumes the read (d+1 -> d, i+1).  gap(L) = o + (L-1)*e, mismatch x — the model of
+// nw_affine_kernel and of the oracle (benchmark_utils.h:139-142,288).  The answer is the first s whose M on diagonal
+// n-m reaches i = m.
+// Exactness of the band: a path that leaves it touches a diagonal |D| = K+1, which costs at least gap(K+1) to reach
+// and gap(K+1-|n-m|) to come back from: bound = 2o + (2K - |n-m|)e.  A banded result s <= bound is therefore the global
+// optimum; pairs that do not finish by then (or with |n-m| > K) are appended to `todo` for the full-matrix kernel.
+// --------------------------------------------------------------------------------------------------------
+#define NW_WFA_K 7
+template <int K, int W64>
+__global__ __launch_bounds__(LEAP_GEN_THREADS) void nw_wfa_kernel(const uint4* __restrict__ planes,
+                                                                  const uint32_t* __restrict__ lens, long n, int w4, int x,
+                                                                  int o, int ext, int gm, int gi, OutMap out,
+                                                                  uint32_t* __restrict__ todo, uint32_t* __restrict__ todo_count) {
+    constexpr int NL = 2 * K + 1, T = LEAP_GEN_THREADS, SLOT = NL * T;
+    extern __shared__ short s_ring[];
+    const int t = threadIdx.x;
+    short* const r_m = s_ring + t;
+    short* const r_i = r_m + gm * SLOT;
+    short* const r_d = r_i + gi * SLOT;
+    const long i = (long)blockIdx.x * T + t;
+    int result = 0;
+    bool unresolved = false;
+    if (i < n) {
+        const uint32_t ln = lens[i];
+        const int m = (int)(ln & 0xffffu), nn = (int)(ln >> 16);
+        const int df = nn - m, adf = df < 0 ? -df : df;
+        if (adf > K) {
+            unresolved = true;
+        } else {
+            VW<W64> A0, A1, B0, B1;
+            load_planes<W64>(planes, n, w4, i, A0, A1, B0, B1);
+            // mismatch-or-outside vector per diagonal, indexed by i: bit p = (A[p] != B[p+d]) or p >= min(m, n-d) or p+d < 0
+            VW<W64> mask[NL];
+#pragma unroll
+            for (int j = 0; j < NL; j++) {
+                const int d = j - K, sft = d < 0 ? -d : d;
+                const int lim = m < nn - d ? m : nn - d;
+                const VW<W64> valid = vw_low_ones<W64>(lim);
+                if (d >= 0) { /* bit p of b = B[p+d]: towards index 0 */
+#pragma unroll
+                    for (int q = 0; q < W64; q++) {
+                        const u64 h0 = q + 1 < W64 ? B0.w[q + 1] : 0ull, h1 = q + 1 < W64 ? B1.w[q + 1] : 0ull;
+                        const u64 b0 = (B0.w[q] >> sft) | (sft ? (h0 << (64 - sft)) : 0ull);
+                        const u64 b1 = (B1.w[q] >> sft) | (sft ? (h1 << (64 - sft)) : 0ull);
+                        mask[j].w[q] = (A0.w[q] ^ b0) | (A1.w[q] ^ b1) | ~valid.w[q];
+                    }
+                } else {
+                    const VW<W64> b0 = vw_away0_small<W64>(B0, sft), b1 = vw_away0_small<W64>(B1, sft);
+                    const VW<W64> low = vw_low_ones<W64>(sft);
+#pragma unroll
+                    for (int q = 0; q < W64; q++) mask[j].w[q] = (A0.w[q] ^ b0.w[q]) | (A1.w[q] ^ b1.w[q]) | ~valid.w[q] | low.w[q];
+                }
+            }
+            const int bound = 2 * o + (2 * K - adf) * ext;
+            result = -1;
+#pragma unroll
+            for (int j = 0; j < NL; j++) r_m[j * T] = -2, r_i[j * T] = -2, r_d[j * T] = -2;
+            {
+                const int e0 = vw_next_one<W64>(mask[K], 0); /* <= min(m, n) */
+                r_m[K * T] = (short)e0;
+                if (df == 0 && e0 >= m) result = 0;
+            }
+            for (int s = 1; s <= bound && result < 0; s++) {
+                const short* const m_o = r_m + ((s - o) & (gm - 1)) * SLOT;
+                const short* const m_x = r_m + ((s - x) & (gm - 1)) * SLOT;
+                const short* const i_e = r_i + ((s - ext) & (gi - 1)) * SLOT;
+                const short* const d_e = r_d + ((s - ext) & (gi - 1)) * SLOT;
+                short* const m_w = r_m + (s & (gm - 1)) * SLOT;
+                short* const i_w = r_i + (s & (gi - 1)) * SLOT;
+                short* const d_w = r_d + (s & (gi - 1)) * SLOT;
+                const bool has_o = s >= o, has_e = s >= ext, has_x = s >= x;
+                int done = 0;
+#pragma unroll
+                for (int j = 0; j < NL; j++) {
+                    const int d = j - K;
+                    const int m_lo = (j > 0 && has_o) ? (int)m_o[(j > 0 ? j - 1 : 0) * T] : -2;
+                    const int i_lo = (j > 0 && has_e) ? (int)i_e[(j > 0 ? j - 1 : 0) * T] : -2;
+                    const int m_hi = (j < NL - 1 && has_o) ? (int)m_o[(j < NL - 1 ? j + 1 : j) * T] : -2;
+                    const int d_hi = (j < NL - 1 && has_e) ? (int)d_e[(j < NL - 1 ? j + 1 : j) * T] : -2;
+                    const int own = has_x ? (int)m_x[j * T] : -2;
+                    int inew = m_lo > i_lo ? m_lo : i_lo;      /* reference character consumed: i stays, j = i + d */
+                    inew = (inew >= 0 && inew + d <= nn) ? inew : -2;
+                    int dnew = m_hi > d_hi ? m_hi : d_hi;      /* read character consumed */
+                    dnew = (dnew >= 0 && dnew + 1 <= m) ? dnew + 1 : -2;
+                    int st = (own >= 0 && own + 1 <= m && own + 1 + d <= nn) ? own + 1 : -2;
+                    st = inew > st ? inew : st;
+                    st = dnew > st ? dnew : st;
+                    int mnew = -2;
+                    if (st >= 0) mnew = vw_next_one<W64>(mask[j], st);
+                    if (d == df && mnew >= m) done = 1;
+                    m_w[j * T] = (short)mnew, i_w[j * T] = (short)inew, d_w[j * T] = (short)dnew;
+                }
+                if (done) result = s;
+            }
+            if (result < 0) unresolved = true;
+        }
+    }
+    // wave-aggregated append of the unresolved pairs
+    const u64 bal = __ballot(unresolved);
+    if (bal) {
+        const int lane = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        uint32_t base = 0;
+        const int leader = __builtin_ctzll(bal);
+        if ((t & 63) == leader) base = atomicAdd(todo_count, (uint32_t)__builtin_popcountll(bal));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+        if (unresolved) todo[base + lane] = (uint32_t)i;
+    }
+    if (i < n && !unresolved) out.put(i, result);
 }
 
 // Persistent, lane-refilling form of leap_unit_kernel<K,W64>: a pair needs final_ED+1 generations (mean ~8, max >30

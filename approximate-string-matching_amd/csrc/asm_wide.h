@@ -273,10 +273,15 @@ static inline void launch_greedy_wide(hipStream_t stream, const uint4* planes, c
 template <int W64, int MAXROWS>
 __global__ __launch_bounds__(64) void nw_affine_kernel(const uint4* __restrict__ planes,
                                                        const uint32_t* __restrict__ lens, long n, int w4, int x,
-                                                       int o, int e, OutMap out) {
+                                                       int o, int e, OutMap out, const uint32_t* __restrict__ todo,
+                                                       const uint32_t* __restrict__ todo_count) {
     __shared__ uint32_t s_bound[MAXROWS + 1][64];
     const int t = threadIdx.x;
-    const long i = (long)blockIdx.x * 64 + t;
+    long i = (long)blockIdx.x * 64 + t;
+    if (todo) { /* second pass of launch_nw_wfa: only the listed bucket slots */
+        if (i >= (long)*todo_count) return;
+        i = (long)todo[i];
+    }
     if (i >= n) return;
     const uint32_t ln = lens[i];
     const int m = (int)(ln & 0xffffu), nn = (int)(ln >> 16);
@@ -354,9 +359,12 @@ static inline void launch_nw_affine(hipStream_t stream, const uint4* planes, con
                                     int maxlen, int x, int o, int e, OutMap out) {
     const dim3 g((unsigned)((n + 63) / 64)), t(64);
     if (maxlen <= 128)
-        hipLaunchKernelGGL((nw_affine_kernel<2, 128>), g, t, 0, stream, planes, lens, (long)n, w4, x, o, e, out);
+        hipLaunchKernelGGL((nw_affine_kernel<2, 128>), g, t, 0, stream, planes, lens, (long)n, w4, x, o, e, out,
+                           (const uint32_t*)nullptr, (const uint32_t*)nullptr);
     else if (maxlen <= 256)
-        hipLaunchKernelGGL((nw_affine_kernel<4, 256>), g, t, 0, stream, planes, lens, (long)n, w4, x, o, e, out);
+        hipLaunchKernelGGL((nw_affine_kernel<4, 256>), g, t, 0, stream, planes, lens, (long)n, w4, x, o, e, out,
+                           (const uint32_t*)nullptr, (const uint32_t*)nullptr);
     else
-        hipLaunchKernelGGL((nw_affine_kernel<8, 512>), g, t, 0, stream, planes, lens, (long)n, w4, x, o, e, out);
+        hipLaunchKernelGGL((nw_affine_kernel<8, 512>), g, t, 0, stream, planes, lens, (long)n, w4, x, o, e, out,
+                           (const uint32_t*)nullptr, (const uint32_t*)nullptr);
 }

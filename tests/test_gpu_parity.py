@@ -88,7 +88,8 @@ def test_band_widths(asm, engine, oracle, k):
     _check(f"leap k={k}", engine.align(batch, asm.LEAP, params), oracle.leap(hb, k=k), hb)
 
 
-@pytest.mark.parametrize("k,x,o,e", [(3, 2, 3, 1), (5, 4, 6, 2), (10, 1, 2, 1), (3, 1, 1, 1), (3, 3, 5, 5), (2, 15, 15, 1)])
+@pytest.mark.parametrize("k,x,o,e", [(3, 2, 3, 1), (5, 4, 6, 2), (10, 1, 2, 1), (3, 1, 1, 1), (3, 3, 5, 5), (2, 15, 15, 1), (3, 9, 12, 3),
+                                     (5, 15, 15, 15), (4, 1, 7, 2), (1, 2, 2, 2)])
 def test_general_penalties(asm, engine, oracle, k, x, o, e):
     """Arbitrary (x, o, e): affine NW, generic LEAP, Greedy costs."""
     cfg, _, _ = asm.workload("C2")
@@ -98,6 +99,22 @@ def test_general_penalties(asm, engine, oracle, k, x, o, e):
     _check("nw", engine.align(batch, asm.NW, params), oracle.nw(hb, x, o, e), hb)
     _check("leap", engine.align(batch, asm.LEAP, params), oracle.leap(hb, k, x, o, e), hb)
     _check("greedy", engine.align(batch, asm.GREEDY, params), oracle.greedy(hb, k, x, o, e, mode=1), hb)
+
+
+@pytest.mark.parametrize("x,o,e", [(2, 3, 1), (4, 6, 2), (5, 2, 2), (1, 4, 1)])
+def test_affine_nw_wavefront_pass_and_full_matrix_fallback(asm, engine, oracle, x, o, e):
+    """Affine NW = banded wavefront pass + full-matrix pass over the pairs the band cannot settle: noisy pairs (most fall
+    back), clean pairs (none do), ragged lengths with |n-m| beyond the band, and the mixed-length workload."""
+    for wl, err, n in (("C2", 0.25, 3000), ("C2", 0.01, 3000), ("C5", None, 3000)):
+        cfg, _, _ = asm.workload(wl)
+        if err is not None:
+            cfg.err = err
+        hb = asm.generate_pairs(cfg, 23, n)
+        batch = engine.upload(hb, asm.GREEDY_CLEAN)
+        _check(f"nw {wl} err={err}", engine.align(batch, asm.NW, asm.Params.default(x=x, o=o, e=e)), oracle.nw(hb, x, o, e), hb)
+    hb = random_ragged_batch(asm, 31, 1500, 0, 250)
+    batch = engine.upload(hb, asm.GREEDY_CLEAN)
+    _check("nw ragged", engine.align(batch, asm.NW, asm.Params.default(x=x, o=o, e=e)), oracle.nw(hb, x, o, e), hb)
 
 
 @pytest.mark.parametrize("x,o,e", [(1, 1, 1), (2, 3, 1)])

@@ -39,6 +39,12 @@ for wl, n, k in (("C2", 12000, 3), ("C5", 6000, 3), ("C3", 1500, 30), ("C2", 200
     want_cost, want_cig = orc.greedy(hb, k=k, mode=0, cigars=True)
     check(wl + " cigar cost", cost, want_cost)
     assert cig == want_cig, wl
+    if wl in ("C2", "C5"):
+        pg = asm.Params.default(k=k, x=2, o=3, e=1)
+        bc = eng.upload(hb, asm.GREEDY_CLEAN)
+        check(wl + " nw affine", eng.align(bc, asm.NW, pg), orc.nw(hb, 2, 3, 1))
+        check(wl + " leap general", eng.align(bc, asm.LEAP, pg), orc.leap(hb, k, 2, 3, 1))
+        check(wl + " greedy general", eng.align(bc, asm.GREEDY, pg), orc.greedy(hb, k, 2, 3, 1, mode=1))
 print("ok")
 """ % ROOT
 
@@ -47,7 +53,7 @@ print("ok")
     {"ASM_PERSIST": "0"},
     {"ASM_PERSIST_LEAP": "1", "ASM_LEAP_HINT": "0"},
     {"ASM_LEAP_HINT": "0"},
-    {"ASM_NW_BANDED": "0"},
+    {"ASM_NW_BANDED": "0", "ASM_NW_WFA": "0"},
     {"ASM_WAVE": "0"},
     {"ASM_BUCKET": "0"},
     {"ASM_REFILL_GREEDY": "1", "ASM_REFILL_LEAP": "64", "ASM_PERSIST_LEAP": "1", "ASM_LEAP_HINT": "0"},
