@@ -25,6 +25,7 @@ HEADER_PATH = os.path.join(_HERE, "..", "include", "asm_mi355x.h")
 NW, LEAP, GREEDY = 0, 1, 2
 ALIGNER_NAMES = {NW: "nw", LEAP: "leap", GREEDY: "greedy"}
 GREEDY_SEQUENTIAL, GREEDY_CLEAN = 0, 1
+FILTER_SEQUENTIAL, FILTER_CLEAN = 0, 1
 GEN_EXACT_ERRORS, GEN_PER_BASE = 0, 1
 GREEDY_MAX_LENGTH = 128
 LEAP_MAX_LENGTH = 256
@@ -127,6 +128,8 @@ def load_library() -> ctypes.CDLL:
         "asm_greedy_cigar_batch_async": (i32, [vp, vp, c.POINTER(Params), vp, vp, i32, vp]),
         "asm_cigar_format": (i32, [vp, i32, i32, vp, c.c_size_t]),
         "asm_coverage": (i32, [vp, vp, c.POINTER(Params), vp, i32, vp, i32, vp, vp, i32, vp, vp]),
+        "asm_simd_ed_batch_async": (i32, [vp, vp, i32, i32, i32, vp, vp]),
+        "asm_shd_filter_batch_async": (i32, [vp, vp, i32, vp]),
         "asm_count_equal_async": (i32, [vp, vp, vp, i64, vp]),
         "asm_accuracy_async": (i32, [vp, vp, vp, vp, vp, i64, vp]),
         "asm_run_benchmark_async": (i32, [vp, vp, c.POINTER(Params), i32, vp, vp, vp, vp, vp]),
@@ -381,6 +384,38 @@ class Engine:
         d_out = self.malloc(4 * max(batch.n, 1))
         try:
             self.align_async(batch, aligner, params, d_out)
+            return self.to_host(d_out, batch.n)
+        finally:
+            self.free(d_out)
+
+    # ---- filtering stage: bit-parallel LEAP (SIMD_ED) and SHD (LEAP_SIMD/main.cpp:95-101,186-195) ----
+    def simd_ed_async(self, batch: DeviceBatch, ed_threshold: int, d_ed: int, shd: bool = True, mode: int = FILTER_CLEAN,
+                      state: Optional[Sequence[int]] = None) -> None:
+        """SIMD_ED::init_levenshtein(ed_threshold, ED_GLOBAL, shd) + load_reads/calculate_masks/reset/run per pair:
+        d_ed[i] = get_ED() when check_pass() else -1.  state = (final_ED, lane distance, converge_ED) carried into the
+        first pair in FILTER_SEQUENTIAL mode."""
+        st = None
+        if state is not None:
+            st = (ctypes.c_int32 * 3)(*[int(v) for v in state])
+        self._chk(self.lib.asm_simd_ed_batch_async(self.h, batch.ptr, int(ed_threshold), 1 if shd else 0, int(mode), st, d_ed))
+
+    def simd_ed(self, batch: DeviceBatch, ed_threshold: int, shd: bool = True, mode: int = FILTER_CLEAN,
+                state: Optional[Sequence[int]] = None) -> np.ndarray:
+        d_out = self.malloc(4 * max(batch.n, 1))
+        try:
+            self.simd_ed_async(batch, ed_threshold, d_out, shd, mode, state)
+            return self.to_host(d_out, batch.n)
+        finally:
+            self.free(d_out)
+
+    def shd_filter_async(self, batch: DeviceBatch, max_error: int, d_pass: int) -> None:
+        """bit_vec_filter_avx(read planes, ref planes, length, max_error): d_pass[i] in {0, 1}."""
+        self._chk(self.lib.asm_shd_filter_batch_async(self.h, batch.ptr, int(max_error), d_pass))
+
+    def shd_filter(self, batch: DeviceBatch, max_error: int) -> np.ndarray:
+        d_out = self.malloc(4 * max(batch.n, 1))
+        try:
+            self.shd_filter_async(batch, max_error, d_out)
             return self.to_host(d_out, batch.n)
         finally:
             self.free(d_out)

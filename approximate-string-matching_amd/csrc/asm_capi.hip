@@ -17,6 +17,7 @@
 #include "asm_wave.h"
 #include "asm_cover.h"
 #include "asm_tails.h"
+#include "asm_filter.h"
 
 struct asm_handle {
     int device = 0;
@@ -211,6 +212,34 @@ static int cover_bucket(asm_handle* h, const asm_bucket& b, const CoverArgs& ca)
     (void)hipFree(d_trace);
     (void)hipFree(d_band);
     return rc;
+}
+
+/* SIMD_ED events of one bucket (asm_filter.h) */
+template <int W64>
+static int launch_simd_ed_events(asm_handle* h, const asm_bucket& b, int T, int shd, OutMap ev) {
+    const dim3 grid((unsigned)((b.n + SIMD_ED_THREADS - 1) / SIMD_ED_THREADS)), block(SIMD_ED_THREADS);
+#define SIMD_ED_CASE(TT)                                                                                                \
+    case TT:                                                                                                            \
+        hipLaunchKernelGGL((simd_ed_kernel<TT, W64>), grid, block, 0, h->stream, b.planes, b.lens, (long)b.n, b.w4, T, shd, ev); \
+        break;
+    switch (T <= ASM_FILTER_REG_MAX_T ? T : 0) {
+        SIMD_ED_CASE(1)
+        SIMD_ED_CASE(2)
+        SIMD_ED_CASE(3)
+        SIMD_ED_CASE(4)
+        SIMD_ED_CASE(5)
+        SIMD_ED_CASE(6)
+        SIMD_ED_CASE(7)
+        SIMD_ED_CASE(8)
+        default: {
+            const size_t lds = (size_t)2 * (2 * T + 3) * SIMD_ED_THREADS * sizeof(short);
+            hipLaunchKernelGGL((simd_ed_kernel<0, W64>), grid, block, lds, h->stream, b.planes, b.lens, (long)b.n, b.w4, T, shd,
+                               ev);
+        }
+    }
+#undef SIMD_ED_CASE
+    HIPCHK(h, hipGetLastError());
+    return ASM_OK;
 }
 
 extern "C" {
@@ -1013,6 +1042,87 @@ int asm_align_batch(asm_handle* h, int aligner, int64_t n, const char* reads, co
     (void)hipFree(d_out);
     batch_release(b);
     return rc;
+}
+
+int asm_simd_ed_batch_async(asm_handle* h, const asm_batch* b, int ed_threshold, int shd_enable, int mode,
+                            const int32_t* state, int32_t* d_ed) {
+    if (!h || !b || !d_ed) return fail(h, ASM_EINVAL, "asm_simd_ed_batch_async: NULL argument");
+    if (ed_threshold < 1 || ed_threshold > ASM_FILTER_MAX_T)
+        return fail(h, ASM_EINVAL, "asm_simd_ed_batch_async: ED threshold must be in [1, 32]");
+    if (shd_enable && ed_threshold > ASM_SHD_MAX_ERROR)
+        return fail(h, ASM_EINVAL, "asm_simd_ed_batch_async: SHD needs an ED threshold <= 16 (MAX_ERROR_AVX)");
+    if (mode != ASM_FILTER_SEQUENTIAL && mode != ASM_FILTER_CLEAN)
+        return fail(h, ASM_EINVAL, "asm_simd_ed_batch_async: unknown mode");
+    if (mode == ASM_FILTER_SEQUENTIAL && state && (state[0] < 0 || state[0] > 255 || state[1] < 0 || state[1] > 255 || state[2] < 0))
+        return fail(h, ASM_EINVAL, "asm_simd_ed_batch_async: state out of range");
+    if (b->n == 0) return ASM_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = ASM_OK;
+    for (int q = 0; q < b->nb && !rc; q++) {
+        OutMap ev;
+        ev.out = d_ed;
+        ev.order = b->bk[q].order;
+        rc = b->bk[q].maxlen <= 128 ? launch_simd_ed_events<2>(h, b->bk[q], ed_threshold, shd_enable ? 1 : 0, ev)
+                                    : launch_simd_ed_events<4>(h, b->bk[q], ed_threshold, shd_enable ? 1 : 0, ev);
+    }
+    if (rc) return rc;
+    const long n = (long)b->n;
+    const dim3 g(grid_for(b->n)), t(ASM_BLOCK);
+    if (mode == ASM_FILTER_CLEAN) {
+        hipLaunchKernelGGL(simd_ed_clean_kernel, g, t, 0, h->stream, d_ed, n, ed_threshold);
+        HIPCHK(h, hipGetLastError());
+        return ASM_OK;
+    }
+    /* sequential: resolve the verdict chain in batch order with two last-setter scans */
+    const int init_fe = state ? state[0] : 0, init_fd = state ? state[1] : 0, init_conv = state ? state[2] : 0;
+    int32_t *d_a = nullptr, *d_b = nullptr;
+    void* d_tmp = nullptr;
+    size_t tmp_bytes = 0;
+    do {
+#define TRY(call)                                                  \
+    if ((call) != hipSuccess) {                                    \
+        rc = fail(h, ASM_ENODEVICE, std::string(#call) + " failed"); \
+        break;                                                     \
+    }
+        TRY(hipMalloc((void**)&d_a, sizeof(int32_t) * (size_t)n));
+        TRY(hipMalloc((void**)&d_b, sizeof(int32_t) * (size_t)n));
+        TRY(hipcub::DeviceScan::InclusiveScan(nullptr, tmp_bytes, d_a, d_b, LastSetter(), (int)n, h->stream));
+        TRY(hipMalloc(&d_tmp, tmp_bytes + 16));
+        hipLaunchKernelGGL(simd_ed_setter_kernel, g, t, 0, h->stream, (const int32_t*)d_ed, n, d_a);
+        TRY(hipcub::DeviceScan::InclusiveScan(d_tmp, tmp_bytes, d_a, d_b, LastSetter(), (int)n, h->stream));
+        hipLaunchKernelGGL(simd_ed_converge_kernel, g, t, 0, h->stream, (const int32_t*)d_ed, (const int32_t*)d_b, n, init_fe,
+                           init_fd, d_a);
+        TRY(hipcub::DeviceScan::InclusiveScan(d_tmp, tmp_bytes, d_a, d_b, LastSetter(), (int)n, h->stream));
+        hipLaunchKernelGGL(simd_ed_verdict_kernel, g, t, 0, h->stream, d_ed, (const int32_t*)d_b, n, ed_threshold, init_conv);
+        TRY(hipGetLastError());
+        TRY(hipStreamSynchronize(h->stream)); /* the scratch below is freed on return */
+#undef TRY
+    } while (0);
+    if (d_a) (void)hipFree(d_a);
+    if (d_b) (void)hipFree(d_b);
+    if (d_tmp) (void)hipFree(d_tmp);
+    return rc;
+}
+
+int asm_shd_filter_batch_async(asm_handle* h, const asm_batch* b, int max_error, int32_t* d_pass) {
+    if (!h || !b || !d_pass) return fail(h, ASM_EINVAL, "asm_shd_filter_batch_async: NULL argument");
+    if (max_error < 0 || max_error > ASM_SHD_MAX_ERROR)
+        return fail(h, ASM_EINVAL, "asm_shd_filter_batch_async: max_error must be in [0, 16] (MAX_ERROR_AVX)");
+    if (b->n == 0) return ASM_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    for (int q = 0; q < b->nb; q++) {
+        const asm_bucket& k = b->bk[q];
+        OutMap out;
+        out.out = d_pass;
+        out.order = k.order;
+        const dim3 g(grid_for(k.n)), t(ASM_BLOCK);
+        if (k.maxlen <= 128)
+            hipLaunchKernelGGL(shd_kernel<2>, g, t, 0, h->stream, k.planes, k.lens, (long)k.n, k.w4, max_error, out);
+        else
+            hipLaunchKernelGGL(shd_kernel<4>, g, t, 0, h->stream, k.planes, k.lens, (long)k.n, k.w4, max_error, out);
+    }
+    HIPCHK(h, hipGetLastError());
+    return ASM_OK;
 }
 
 int asm_count_equal_async(asm_handle* h, const int32_t* d_a, const int32_t* d_b, int64_t n, unsigned long long* d_count) {

@@ -1,0 +1,327 @@
+// Bit-parallel LEAP (SIMD_ED, Levenshtein mode, ED_GLOBAL) and the SHD pre-filter of GASMA/benchmark/LEAP_SIMD — the
+// filtering stage in front of the aligners (driver LEAP_SIMD/main.cpp:95-101,186-195).  One thread per
+// pair on the batch's 2-bit planes; vectors are W64 64-bit words (2: length <= 128, 4: <= 256 = _MAX_LENGTH_).
+//
+// Reference behaviour kept on purpose (oracle/asm_oracle_filter.c S1-S4):
+//  S1  the reference's 256-bit shifts move each 128-bit half on its own (shift.cpp:33-61);
+//  S2  SIMD_ED's verdict state (final_ED, final lane, converge_ED) flows from pair to pair: the kernels emit one *event*
+//      per pair and, in sequential mode, two scans resolve the chain in batch order (simd_ed_*_kernel below);
+//  S3  the mask-array SHD inside SIMD_ED amends nothing and masks the main lane with bits 0..254 (SHD.cpp:324-372);
+//  S4  a lane that starts at or beyond the end reaches the end (SIMD_ED.cpp:57-60).
+#pragma once
+#include "asm_kernels.h"
+
+#define ASM_FILTER_MAX_T 32    /* lanes 2T+1 <= 65 */
+#define ASM_FILTER_REG_MAX_T 8 /* masks of all lanes held in registers up to here; computed per use beyond */
+#define ASM_SHD_MAX_ERROR 16   /* MAX_ERROR_AVX (LEAP_SIMD/mask.h:21): rows of the reference's begin-mask table */
+
+// events of one pair (S2)
+#define EV_REJECTED (-1)  /* SHD said no: verdict fail, state untouched                                             */
+#define EV_NOT_REACHED (-2) /* no lane reached the end within T generations: verdict = the carried state's             */
+#define EV_EXACT (-3)     /* the main lane reached the end at e = 0: passes, sets (final_ED, lane) = (0, 0) only       */
+/* >= 0: reached at generation fe on a lane fd away from the main one: fe | fd << 8                                     */
+
+// bits move away from index 0 by s in [0, 63], each 128-bit half separately when W64 = 4 (S1)
+template <int W64>
+ASM_DEV VW<W64> avx_away0(const VW<W64>& v, int s) {
+    VW<W64> r;
+#pragma unroll
+    for (int q = 0; q < W64; q++) {
+        const u64 lo = (q & 1) ? v.w[q - 1] : 0ull; /* nothing crosses an even word boundary */
+        r.w[q] = (v.w[q] << s) | (s ? (lo >> (64 - s)) : 0ull);
+    }
+    return r;
+}
+
+// hamming mask of lane d = l - mid in [-T, T] (SIMD_ED::calculate_masks, SIMD_ED.cpp:180-212): d < 0 shifts the reference,
+// d > 0 the read
+template <int W64>
+ASM_DEV VW<W64> simd_lane_mask(const VW<W64>& A0, const VW<W64>& A1, const VW<W64>& B0, const VW<W64>& B1, int d) {
+    VW<W64> r;
+    const int s = d < 0 ? -d : d;
+    if (d < 0) {
+        const VW<W64> b0 = avx_away0<W64>(B0, s), b1 = avx_away0<W64>(B1, s);
+#pragma unroll
+        for (int q = 0; q < W64; q++) r.w[q] = (A0.w[q] ^ b0.w[q]) | (A1.w[q] ^ b1.w[q]);
+    } else {
+        const VW<W64> a0 = avx_away0<W64>(A0, s), a1 = avx_away0<W64>(A1, s);
+#pragma unroll
+        for (int q = 0; q < W64; q++) r.w[q] = (a0.w[q] ^ B0.w[q]) | (a1.w[q] ^ B1.w[q]);
+    }
+    return r;
+}
+
+// end position of the run of matches that starts at st (start + count_ID_length_avx, SIMD_ED.cpp:10-61): the next set bit
+// of the lane mask, capped at len.  The reference shifts the mask down by st half by half (S1), so for st < 128 the bits
+// 128 .. 127+st never arrive and read as matches.
+template <int W64>
+ASM_DEV int simd_extend(const VW<W64>& mask, int st, int len) {
+    if (st >= len) return len; /* S4: st + (len - st) */
+    VW<W64> v = mask;
+    if (W64 == 4 && st < 128) {
+        v.w[2] &= st >= 64 ? 0ull : (~0ull << st);
+        if (st > 64) v.w[3] &= ~0ull << (st - 64);
+    }
+    const int r = vw_next_one<W64>(v, st);
+    return r < len ? r : len;
+}
+
+// popcount_SHD_avx (popcount.cpp:44-76,78-110): per nibble, the number of runs of ones
+template <int W64>
+ASM_DEV int shd_popcount(const VW<W64>& v) {
+    int s = 0;
+#pragma unroll
+    for (int q = 0; q < W64; q++) s += __builtin_popcountll(v.w[q] & ~((v.w[q] << 1) & 0xeeeeeeeeeeeeeeeeull));
+    return s;
+}
+
+template <int W64>
+ASM_DEV VW<W64> vw_from(int cnt) { /* bits cnt.. set: MASK_AVX_BEG row cnt-1 (mask.cpp:149-166) */
+    VW<W64> r = vw_low_ones<W64>(cnt);
+#pragma unroll
+    for (int q = 0; q < W64; q++) r.w[q] = ~r.w[q];
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// SIMD_ED::run_levenshtein for one pair (SIMD_ED.cpp:269-352) -> event.  TT > 0: T = TT at compile time, all lane masks in
+// registers, lanes unrolled.  TT = 0: T at run time, lane masks rebuilt per use, the previous generation's end positions in
+// a thread-private LDS column.
+// ---------------------------------------------------------------------------------------------------------------------
+#define SIMD_ED_THREADS 128
+template <int TT, int W64>
+__global__ __launch_bounds__(SIMD_ED_THREADS) void simd_ed_kernel(const uint4* __restrict__ planes,
+                                                                  const uint32_t* __restrict__ lens, long n, int w4, int t_rt,
+                                                                  int shd_enable, OutMap events) {
+    constexpr int NLC = TT > 0 ? 2 * TT + 1 : 1;
+    extern __shared__ short s_end[]; /* TT = 0: [2][2T+3][threads] */
+    const int T = TT > 0 ? TT : t_rt;
+    const int NL = 2 * T + 1;
+    const int t = threadIdx.x;
+    const long i = (long)blockIdx.x * SIMD_ED_THREADS + t;
+    if (i >= n) return;
+    const int m = (int)(lens[i] & 0xffffu);
+    const int len = m > 64 * W64 ? 64 * W64 : m; /* main.cpp:131-132: the read's length, at most _MAX_LENGTH_ */
+    VW<W64> A0, A1, B0, B1;
+    load_planes<W64>(planes, n, w4, i, A0, A1, B0, B1);
+    {   /* strncpy(A/B, ., length): what lies beyond is never compared, but clear it so that shifts bring in zeros only */
+        const VW<W64> lm = vw_low_ones<W64>(len);
+#pragma unroll
+        for (int q = 0; q < W64; q++) A0.w[q] &= lm.w[q], A1.w[q] &= lm.w[q], B0.w[q] &= lm.w[q], B1.w[q] &= lm.w[q];
+    }
+    VW<W64> hm[NLC];
+    if (TT > 0) {
+#pragma unroll
+        for (int j = 0; j < NLC; j++) hm[j] = simd_lane_mask<W64>(A0, A1, B0, B1, j - TT);
+    }
+    if (shd_enable) { /* bit_vec_filter_avx(hamming_masks + 1, buffer_length, ED_t), S3 */
+        const VW<W64> lm = vw_low_ones<W64>(len);
+        VW<W64> diff = lm;
+        if (TT > 0) {
+#pragma unroll
+            for (int j = 0; j < NLC; j++) {
+                const int s = j < TT ? TT - j : j - TT;
+                const VW<W64> tm = s ? vw_from<W64>(s) : vw_low_ones<W64>(255);
+#pragma unroll
+                for (int q = 0; q < W64; q++) diff.w[q] &= hm[j].w[q] & tm.w[q];
+            }
+        } else {
+            for (int j = 0; j < NL; j++) {
+                const int s = j < T ? T - j : j - T;
+                const VW<W64> tm = s ? vw_from<W64>(s) : vw_low_ones<W64>(255);
+                const VW<W64> h = simd_lane_mask<W64>(A0, A1, B0, B1, j - T);
+#pragma unroll
+                for (int q = 0; q < W64; q++) diff.w[q] &= h.w[q] & tm.w[q];
+            }
+        }
+        if (shd_popcount<W64>(diff) > T) {
+            events.put(i, EV_REJECTED);
+            return;
+        }
+    }
+    int ev = EV_NOT_REACHED;
+    if (TT > 0) {
+        int prev[NLC + 2]; /* end[.][e-1] with the two guard lanes; -2 = never written (SIMD_ED.cpp:236-241) */
+#pragma unroll
+        for (int j = 0; j < NLC + 2; j++) prev[j] = -2;
+        prev[TT + 1] = simd_extend<W64>(hm[TT], 0, len);
+        if (prev[TT + 1] == len) ev = EV_EXACT; /* SIMD_ED.cpp:291-296 */
+        for (int e = 1; e <= TT && ev == EV_NOT_REACHED; e++) {
+            int cur[NLC + 2];
+            cur[0] = cur[NLC + 1] = -2;
+#pragma unroll
+            for (int j = 0; j < NLC; j++) {
+                const int dist = j < TT ? TT - j : j - TT;
+                int st = prev[j + 1] + 1; /* SIMD_ED.cpp:318-323 */
+                const int up = prev[j] + (j >= TT ? 1 : 0), dn = prev[j + 2] + (j <= TT ? 1 : 0);
+                st = up > st ? up : st;
+                st = dn > st ? dn : st;
+                int en = -2;
+                if (dist <= e) { /* cur_ED[l] == e */
+                    en = simd_extend<W64>(hm[j], st, len);
+                    if (en == len && ev == EV_NOT_REACHED) ev = e | (dist << 8); /* the lowest lane wins (:334-340) */
+                }
+                cur[j + 1] = en;
+            }
+#pragma unroll
+            for (int j = 0; j < NLC + 2; j++) prev[j] = cur[j];
+        }
+    } else {
+        const int rows = NL + 2;
+        short* const col = s_end + t;
+#define END_AT(g, l) col[((g)*rows + (l)) * SIMD_ED_THREADS]
+        for (int l = 0; l < rows; l++) END_AT(0, l) = -2, END_AT(1, l) = -2;
+        {
+            const VW<W64> h = simd_lane_mask<W64>(A0, A1, B0, B1, 0);
+            const int e0 = simd_extend<W64>(h, 0, len);
+            END_AT(0, T + 1) = (short)e0;
+            if (e0 == len) ev = EV_EXACT;
+        }
+        for (int e = 1; e <= T && ev == EV_NOT_REACHED; e++) {
+            const int gp = (e - 1) & 1, gc = e & 1;
+            for (int j = T - e; j <= T + e; j++) { /* lanes with distance <= e, ascending */
+                int st = (int)END_AT(gp, j + 1) + 1;
+                const int up = (int)END_AT(gp, j) + (j >= T ? 1 : 0), dn = (int)END_AT(gp, j + 2) + (j <= T ? 1 : 0);
+                st = up > st ? up : st;
+                st = dn > st ? dn : st;
+                const VW<W64> h = simd_lane_mask<W64>(A0, A1, B0, B1, j - T);
+                const int en = simd_extend<W64>(h, st, len);
+                END_AT(gc, j + 1) = (short)en;
+                if (en == len) {
+                    const int dist = j < T ? T - j : j - T;
+                    ev = e | (dist << 8);
+                    break;
+                }
+            }
+        }
+#undef END_AT
+    }
+    events.put(i, ev);
+}
+
+// clean mode: every pair judged alone — never reached: fail; exact: 0; reached: final_ED + lane distance if <= T
+__global__ __launch_bounds__(ASM_BLOCK) void simd_ed_clean_kernel(int32_t* __restrict__ ev_to_ed, long n, int T) {
+    const long i = (long)blockIdx.x * ASM_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int ev = ev_to_ed[i];
+    int ed = -1;
+    if (ev == EV_EXACT) ed = 0;
+    if (ev >= 0) {
+        const int conv = (ev & 0xff) + (ev >> 8);
+        ed = conv <= T ? conv : -1;
+    }
+    ev_to_ed[i] = ed;
+}
+
+// sequential mode, step 1: key of the (final_ED, lane) chain — pairs that set it carry fe | fd << 8, the others -1
+__global__ __launch_bounds__(ASM_BLOCK) void simd_ed_setter_kernel(const int32_t* __restrict__ ev, long n,
+                                                                   int32_t* __restrict__ key) {
+    const long i = (long)blockIdx.x * ASM_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int e = ev[i];
+    key[i] = e == EV_EXACT ? 0 : (e >= 0 ? e : -1);
+}
+
+// step 2 (after the last-setter scan of key): converge_ED is rewritten by pairs that run to the end of run_levenshtein
+// (reached or not) from the state in force; exact and rejected pairs leave it alone
+__global__ __launch_bounds__(ASM_BLOCK) void simd_ed_converge_kernel(const int32_t* __restrict__ ev,
+                                                                     const int32_t* __restrict__ state_after, long n,
+                                                                     int init_fe, int init_fd, int32_t* __restrict__ conv_key) {
+    const long i = (long)blockIdx.x * ASM_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int e = ev[i];
+    int k = -1;
+    if (e >= 0 || e == EV_NOT_REACHED) {
+        const int s = state_after[i];
+        k = s >= 0 ? (s & 0xff) + (s >> 8) : init_fe + init_fd;
+    }
+    conv_key[i] = k;
+}
+
+// step 3 (after the last-setter scan of conv_key): the verdicts
+__global__ __launch_bounds__(ASM_BLOCK) void simd_ed_verdict_kernel(int32_t* __restrict__ ev_to_ed,
+                                                                    const int32_t* __restrict__ conv_after, long n, int T,
+                                                                    int init_conv) {
+    const long i = (long)blockIdx.x * ASM_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int e = ev_to_ed[i];
+    int ed = -1;
+    if (e == EV_EXACT) { /* passes; get_ED() is the converge_ED left by the pairs before it (S2) */
+        const int c = i > 0 ? conv_after[i - 1] : -1;
+        ed = c >= 0 ? c : init_conv;
+    } else if (e != EV_REJECTED) {
+        const int c = conv_after[i];
+        ed = c <= T ? c : -1;
+    }
+    ev_to_ed[i] = ed;
+}
+
+struct LastSetter { /* scan operator: the most recent non-negative key */
+    __host__ __device__ int32_t operator()(int32_t a, int32_t b) const { return b >= 0 ? b : a; }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// SHD on the planes: bit_vec_filter_avx(read0, read1, ref0, ref1, length, max_error) (SHD.cpp:241-322).
+// ---------------------------------------------------------------------------------------------------------------------
+// the four in-byte windows of flip_false_zero (SHD.cpp:95-122): in bits i..i+3 of every byte, every zero between the lowest
+// and the highest set bit is set (MASK_SRS, mask.cpp:427-432); the windows are applied one after the other
+ASM_DEV u64 srs_round_word(u64 w) {
+    const u64 NIB = 0x0f0f0f0f0f0f0f0full;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const u64 nb = (w >> i) & NIB;
+        const u64 below = nb | (nb << 1) | (nb << 2) | (nb << 3); /* a set bit at or below */
+        const u64 above = nb | (nb >> 1) | (nb >> 2) | (nb >> 3); /* a set bit at or above */
+        w |= (below & above & NIB) << i;
+    }
+    return w;
+}
+
+template <int W64>
+ASM_DEV VW<W64> shd_flip_false_zero(VW<W64> v) { /* SHD.cpp:95-143 */
+#pragma unroll
+    for (int q = 0; q < W64; q++) v.w[q] = srs_round_word(v.w[q]);
+    VW<W64> sv = avx_away0<W64>(v, 4); /* the windows that straddle a byte boundary */
+#pragma unroll
+    for (int q = 0; q < W64; q++) sv.w[q] = srs_round_word(sv.w[q]);
+#pragma unroll
+    for (int q = 0; q < W64; q++) { /* shift_left_avx(., 4): back towards index 0, half by half */
+        const u64 hi = (q & 1) ? 0ull : sv.w[q + 1];
+        v.w[q] |= (sv.w[q] >> 4) | (hi << 60);
+    }
+    return v;
+}
+
+template <int W64>
+__global__ __launch_bounds__(ASM_BLOCK) void shd_kernel(const uint4* __restrict__ planes, const uint32_t* __restrict__ lens,
+                                                        long n, int w4, int max_error, OutMap out) {
+    const long i = (long)blockIdx.x * ASM_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int m = (int)(lens[i] & 0xffffu);
+    const int len = m > 64 * W64 ? 64 * W64 : m;
+    VW<W64> A0, A1, B0, B1;
+    load_planes<W64>(planes, n, w4, i, A0, A1, B0, B1);
+    const VW<W64> lm = vw_low_ones<W64>(len);
+#pragma unroll
+    for (int q = 0; q < W64; q++) A0.w[q] &= lm.w[q], A1.w[q] &= lm.w[q], B0.w[q] &= lm.w[q], B1.w[q] &= lm.w[q];
+    VW<W64> diff;
+#pragma unroll
+    for (int q = 0; q < W64; q++) diff.w[q] = (A0.w[q] ^ B0.w[q]) | (A1.w[q] ^ B1.w[q]);
+    diff = shd_flip_false_zero<W64>(diff);
+    for (int j = 1; j <= max_error; j++) {
+        const VW<W64> tm = vw_from<W64>(j);
+        VW<W64> t = simd_lane_mask<W64>(A0, A1, B0, B1, j); /* read shifted by j against the reference */
+#pragma unroll
+        for (int q = 0; q < W64; q++) t.w[q] &= tm.w[q] & lm.w[q];
+        t = shd_flip_false_zero<W64>(t);
+#pragma unroll
+        for (int q = 0; q < W64; q++) diff.w[q] &= t.w[q];
+        t = simd_lane_mask<W64>(A0, A1, B0, B1, -j); /* reference shifted by j against the read */
+#pragma unroll
+        for (int q = 0; q < W64; q++) t.w[q] &= tm.w[q] & lm.w[q];
+        t = shd_flip_false_zero<W64>(t);
+#pragma unroll
+        for (int q = 0; q < W64; q++) diff.w[q] &= t.w[q];
+    }
+    out.put(i, shd_popcount<W64>(diff) > max_error ? 0 : 1);
+}

@@ -154,6 +154,25 @@ int asm_coverage(asm_handle* h, const asm_batch* b, const asm_params* p, const u
 int asm_align_batch(asm_handle* h, int aligner, int64_t n, const char* reads, const uint32_t* read_off,
                     const char* refs, const uint32_t* ref_off, const asm_params* p, int greedy_mode,
                     int32_t* penalties);
+/* ---- filtering stage in front of the aligners: bit-parallel LEAP (SIMD_ED) and SHD ------------------------------
+ * Replaces, per pair of the batch, the stdin filter driver's sequence (GASMA/benchmark/LEAP_SIMD/main.cpp:95-101,
+ * 186-195): SIMD_ED::init_levenshtein(ed_threshold, ED_GLOBAL, shd_enable) once, then load_reads(read, ref,
+ * min(m, 256)) / calculate_masks() / reset() / run() / check_pass() / get_ED()  (SIMD_ED.h:47-70, SIMD_ED.cpp:269-352,
+ * 748-753).  d_ed[i] = get_ED() (converge_ED) when check_pass() holds, -1 otherwise.
+ * mode: the reference keeps its verdict state from pair to pair (a pair that never reaches the end inherits the verdict
+ * of the last pair that did; an exact pair reports the previous converge_ED) — ASM_FILTER_SEQUENTIAL reproduces that in
+ * batch order, starting from state = {final_ED, lane distance, converge_ED} (NULL: zeros; the reference leaves them
+ * uninitialised), ASM_FILTER_CLEAN judges every pair on its own (never reached: -1; exact: 0).
+ * ed_threshold in [1, 32]; with shd_enable at most 16 (MAX_ERROR_AVX, LEAP_SIMD/mask.h:21).  Enqueue only in clean
+ * mode; sequential mode returns after its scans have run. */
+#define ASM_FILTER_SEQUENTIAL 0
+#define ASM_FILTER_CLEAN 1
+int asm_simd_ed_batch_async(asm_handle* h, const asm_batch* b, int ed_threshold, int shd_enable, int mode,
+                            const int32_t* state, int32_t* d_ed);
+/* bit_vec_filter_avx(read planes, ref planes, min(m, 256), max_error) (LEAP_SIMD/SHD.h:17-18, SHD.cpp:241-322):
+ * d_pass[i] = 1 when the pair survives the shifted-Hamming-distance filter, 0 when it is rejected.  max_error in
+ * [0, 16].  Enqueue only. */
+int asm_shd_filter_batch_async(asm_handle* h, const asm_batch* b, int max_error, int32_t* d_pass);
 /* accuracy counter of benchmark_utils.h:253-255: *d_count += #{i : a[i] == b[i]} (device pointers; enqueue
  * only; the caller zeroes *d_count). */
 int asm_count_equal_async(asm_handle* h, const int32_t* d_a, const int32_t* d_b, int64_t n,

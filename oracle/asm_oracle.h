@@ -70,6 +70,24 @@ int orc_coverage_batch(int64_t n, const char* reads, const uint32_t* read_off, c
                        const uint32_t* ref_off, const char* cigars1, int stride1, int thr1,
                        const char* cigars2, int stride2, int thr2, uint8_t* out);
 
+/* ---- bit-parallel LEAP (SIMD_ED) and SHD pre-filter: asm_oracle_filter.c ------------------------------------------ */
+#define ORC_FILTER_SEQUENTIAL 0 /* reference as run: the verdict state flows from pair to pair (S2)      */
+#define ORC_FILTER_CLEAN 1      /* every pair judged alone                                               */
+
+/* SIMD_ED::init_levenshtein(ed_t, ED_GLOBAL, shd_enable) then, per pair, load_reads(read, ref, min(m,256)) /
+ * calculate_masks / reset / run (GASMA/benchmark/LEAP_SIMD/SIMD_ED.cpp:10-61,140-212,214-268,269-352; driver
+ * LEAP_SIMD/main.cpp:95-101,186-195).  pass[i] = check_pass(); ed[i] = get_ED() (= converge_ED, :748-753) when it
+ * passes, else -1; ed_raw (optional) = get_ED() whatever the verdict.  state = {final_ED, lane distance, converge_ED}
+ * before the first pair (the reference leaves them uninitialised).  shd_enable needs ed_t <= 16 (MAX_ERROR_AVX). */
+int orc_simd_ed_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
+                      int ed_t, int shd_enable, int mode, const int32_t* state, int32_t* ed, int32_t* ed_raw,
+                      uint8_t* pass);
+
+/* SHD on the pair's 2-bit planes: bit_vec_filter_avx(read0, read1, ref0, ref1, min(m,256), max_error)
+ * (GASMA/benchmark/LEAP_SIMD/SHD.cpp:95-143,241-322; popcount.cpp:44-76,78-110).  pass[i] in {0,1}. */
+int orc_shd_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
+                  int max_error, int32_t* pass);
+
 /* number of OpenMP threads the batch entry points will use (LEAP/NW/Greedy-clean are parallel over pairs;
  * Greedy-sequential resolves views serially first, then runs pairs in parallel). */
 int orc_set_threads(int nthreads);

@@ -1,0 +1,250 @@
+/* TEST INFRASTRUCTURE ONLY — oracle, part 2: the bit-parallel LEAP (SIMD_ED, Levenshtein mode, ED_GLOBAL) and the SHD
+ * pre-filter of GASMA/benchmark/LEAP_SIMD, restated in plain C on 4 x 64-bit words.  See asm_oracle.h for the rules that
+ * apply to everything under oracle/.  Pinned against oracle/_ref/libasm_ref_simd.so (the real sources compiled in place)
+ * by tests/test_oracle_vs_reference.py and tests/golden/.
+ *
+ * Behaviour kept because the reference has it (each is visible in the compiled reference's outputs):
+ *  S1  shift_right_avx / shift_left_avx move each 128-bit half on its own: nothing crosses bit 127 <-> 128
+ *      (shift.cpp:33-61, _mm256_slli_si256 / _mm256_srli_si256 are per-lane byte shifts).
+ *  S2  SIMD_ED keeps final_ED, final_lane_idx and converge_ED from pair to pair (SIMD_ED.cpp:258-268 resets only
+ *      ED_pass / cur_ED): a pair that never reaches the end gets the verdict of the last pair that did
+ *      (SIMD_ED.cpp:348-351), an exact pair returns before converge_ED is written (:291-296) so get_ED() is the
+ *      previous pair's value.  ORC_FILTER_SEQUENTIAL carries that state; ORC_FILTER_CLEAN judges every pair alone
+ *      (never reached -> fail, exact -> 0).
+ *  S3  bit_vec_filter_avx(masks, length, max_error) amends its *mask*, not the data (SHD.cpp:353: flip_false_zero is
+ *      applied to temp_mask after temp_diff was taken), i.e. no amendment at all; and for the main lane it reads table
+ *      row -1 of MASK_AVX_BEG (:349-350) — the 32 bytes in front of the table, which in the reference library as GCC lays
+ *      it out are the last row of MASK_AVX_END: bits 0..254 set.  (Layout dependent; modelled as built here.)
+ *  S4  count_ID_length_avx with start_pos >= buffer_length returns buffer_length - start_pos (<= 0) (SIMD_ED.cpp:57-60).
+ */
+#include "asm_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+    uint64_t w[4];
+} v256;
+
+static inline uint64_t shl64(uint64_t v, int n) { return n >= 64 ? 0 : v << n; } /* x86 vector shifts: count >= 64 gives 0 */
+static inline uint64_t shr64(uint64_t v, int n) { return n >= 64 ? 0 : v >> n; }
+
+/* shift_right_avx (shift.cpp:33-46): bits move towards higher indexes */
+static v256 avx_shr(v256 v, int n) {
+    if (n >= 128) {
+        v.w[2] = v.w[0], v.w[3] = v.w[1], v.w[0] = v.w[1] = 0;
+        n %= 128;
+    }
+    if (n >= 64) {
+        v.w[1] = v.w[0], v.w[3] = v.w[2], v.w[0] = v.w[2] = 0;
+        n %= 64;
+    }
+    v256 c = {{0, v.w[0], 0, v.w[2]}};
+    v256 r;
+    for (int q = 0; q < 4; q++) r.w[q] = shl64(v.w[q], n) | shr64(c.w[q], 64 - n);
+    return r;
+}
+
+/* shift_left_avx (shift.cpp:48-61): bits move towards index 0 */
+static v256 avx_shl(v256 v, int n) {
+    if (n >= 128) {
+        v.w[0] = v.w[2], v.w[1] = v.w[3], v.w[2] = v.w[3] = 0;
+        n %= 128;
+    }
+    if (n >= 64) {
+        v.w[0] = v.w[1], v.w[2] = v.w[3], v.w[1] = v.w[3] = 0;
+        n %= 64;
+    }
+    v256 c = {{v.w[1], 0, v.w[3], 0}};
+    v256 r;
+    for (int q = 0; q < 4; q++) r.w[q] = shr64(v.w[q], n) | shl64(c.w[q], 64 - n);
+    return r;
+}
+
+static inline v256 v_and(v256 a, v256 b) {
+    v256 r;
+    for (int q = 0; q < 4; q++) r.w[q] = a.w[q] & b.w[q];
+    return r;
+}
+static inline v256 v_or(v256 a, v256 b) {
+    v256 r;
+    for (int q = 0; q < 4; q++) r.w[q] = a.w[q] | b.w[q];
+    return r;
+}
+static inline v256 v_xor(v256 a, v256 b) {
+    v256 r;
+    for (int q = 0; q < 4; q++) r.w[q] = a.w[q] ^ b.w[q];
+    return r;
+}
+static v256 low_ones(int len) { /* MASK_AVX_END row `len` (mask.cpp:168-425); all ones from 256 on */
+    v256 r;
+    for (int q = 0; q < 4; q++) {
+        int rel = len - 64 * q;
+        r.w[q] = rel <= 0 ? 0 : (rel >= 64 ? ~0ull : ((1ull << rel) - 1));
+    }
+    return r;
+}
+static v256 not_low_ones(int cnt) { /* MASK_AVX_BEG row cnt-1 (mask.cpp:149-166): the first cnt bits cleared */
+    v256 r = low_ones(cnt);
+    for (int q = 0; q < 4; q++) r.w[q] = ~r.w[q];
+    return r;
+}
+
+/* 2-bit planes as avx_convert2bit leaves them (bit_convert.cpp:335-479): C = 01, G = 10, T = 11, any other byte 00;
+ * bit p of plane b = bit b of the code of character p.  Characters at and beyond `len` are NUL padding (code 00). */
+static void planes_of(const char* s, int len, v256* p0, v256* p1) {
+    memset(p0, 0, sizeof *p0);
+    memset(p1, 0, sizeof *p1);
+    for (int p = 0; p < len && p < 256; p++) {
+        int code = s[p] == 'C' ? 1 : (s[p] == 'G' ? 2 : (s[p] == 'T' ? 3 : 0));
+        if (code & 1) p0->w[p >> 6] |= 1ull << (p & 63);
+        if (code & 2) p1->w[p >> 6] |= 1ull << (p & 63);
+    }
+}
+
+/* number of nibbles' runs of ones: POPCOUNT_SHD (popcount.cpp:44-76) summed over all 64 nibbles */
+static int popcount_shd(v256 v) {
+    static const uint8_t T[16] = {0, 1, 1, 1, 1, 2, 2, 1, 1, 2, 2, 2, 1, 2, 1, 1};
+    int s = 0;
+    for (int q = 0; q < 4; q++)
+        for (int b = 0; b < 64; b += 4) s += T[(v.w[q] >> b) & 15];
+    return s;
+}
+
+/* one round of the four in-byte windows of flip_false_zero (SHD.cpp:95-122): window bits i..i+3 of every byte are
+ * looked up in MASK_SRS (mask.cpp:427-432: every zero between the lowest and highest set bit of the nibble is set) */
+static v256 srs_round(v256 v) {
+    static const uint8_t SRS[16] = {0x0, 0x1, 0x2, 0x3, 0x4, 0x7, 0x6, 0x7, 0x8, 0xf, 0xe, 0xf, 0xc, 0xf, 0xe, 0xf};
+    for (int i = 0; i < 4; i++)
+        for (int q = 0; q < 4; q++) {
+            uint64_t add = 0;
+            for (int b = 0; b < 8; b++) {
+                unsigned byte = (unsigned)(v.w[q] >> (8 * b)) & 0xffu;
+                add |= (uint64_t)((SRS[(byte >> i) & 15] << i) & 0xff) << (8 * b);
+            }
+            v.w[q] |= add;
+        }
+    return v;
+}
+
+static v256 flip_false_zero(v256 v) { /* SHD.cpp:95-143 */
+    v = srs_round(v);
+    v256 sv = srs_round(avx_shr(v, 4)); /* the windows that straddle a byte boundary */
+    return v_or(avx_shl(sv, 4), v);
+}
+
+/* bit_vec_filter_avx(read planes, ref planes, length, max_error), SHD.cpp:241-322 */
+static int shd_planes(v256 a0, v256 a1, v256 b0, v256 b1, int length, int max_error) {
+    const v256 mask = low_ones(length >= 256 ? 256 : length);
+    a0 = v_and(a0, mask), a1 = v_and(a1, mask), b0 = v_and(b0, mask), b1 = v_and(b1, mask);
+    v256 diff = flip_false_zero(v_or(v_xor(a0, b0), v_xor(a1, b1)));
+    for (int j = 1; j <= max_error; j++) {
+        const v256 tm = v_and(not_low_ones(j), mask);
+        v256 t = v_or(v_xor(avx_shr(a0, j), b0), v_xor(avx_shr(a1, j), b1));
+        diff = v_and(diff, flip_false_zero(v_and(t, tm)));
+        t = v_or(v_xor(avx_shr(b0, j), a0), v_xor(avx_shr(b1, j), a1));
+        diff = v_and(diff, flip_false_zero(v_and(t, tm)));
+    }
+    return popcount_shd(diff) > max_error ? 0 : 1;
+}
+
+int orc_shd_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
+                  int max_error, int32_t* pass) {
+    if (max_error < 0 || max_error > 16) return -1; /* MAX_ERROR_AVX rows in MASK_AVX_BEG (mask.h:21) */
+    for (int64_t i = 0; i < n; i++) {
+        const int m = (int)(read_off[i + 1] - read_off[i]), nn = (int)(ref_off[i + 1] - ref_off[i]);
+        const int length = m > 256 ? 256 : m;
+        v256 a0, a1, b0, b1;
+        planes_of(reads + read_off[i], length, &a0, &a1);
+        planes_of(refs + ref_off[i], nn, &b0, &b1);
+        pass[i] = shd_planes(a0, a1, b0, b1, length, max_error);
+    }
+    return 0;
+}
+
+/* count_ID_length_avx (SIMD_ED.cpp:10-61) */
+static int count_id(v256 mask, int start, int len) {
+    if (start >= len) return len - start; /* S4 */
+    const v256 s = avx_shl(mask, start);
+    int res = 0;
+    for (int i = 0; i <= (len - start - 1) / 64; i++) {
+        if (s.w[i] == 0) {
+            res += 64;
+        } else {
+            res += __builtin_ctzll(s.w[i]);
+            break;
+        }
+    }
+    return res < len - start ? res : len - start;
+}
+
+#define SIMD_MAX_T 32
+
+/* state[0..2] = final_ED, |final_lane_idx - mid_lane|, converge_ED carried into the first pair (sequential mode) */
+int orc_simd_ed_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
+                      int ed_t, int shd_enable, int mode, const int32_t* state, int32_t* ed, int32_t* ed_raw,
+                      uint8_t* pass) {
+    if (ed_t < 0 || ed_t > SIMD_MAX_T || (shd_enable && ed_t > 16)) return -1;
+    const int lanes = 2 * ed_t + 3, mid = ed_t + 1; /* SIMD_ED.cpp:222-223; lanes 0 and lanes-1 are guards */
+    int fe = state ? state[0] : 0, fd = state ? state[1] : 0, conv = state ? state[2] : 0;
+    v256 hm[2 * SIMD_MAX_T + 3];
+    int end[2 * SIMD_MAX_T + 3][SIMD_MAX_T + 1];
+    for (int64_t i = 0; i < n; i++) {
+        const int m = (int)(read_off[i + 1] - read_off[i]), nn = (int)(ref_off[i + 1] - ref_off[i]);
+        const int len = m > 256 ? 256 : m; /* main.cpp:131-132; SIMD_ED.cpp:140-151 */
+        if (mode == ORC_FILTER_CLEAN) fe = ed_t + 1, fd = 0, conv = 0;
+        v256 a0, a1, b0, b1;
+        planes_of(reads + read_off[i], len, &a0, &a1);
+        planes_of(refs + ref_off[i], nn < len ? nn : len, &b0, &b1); /* strncpy(B, ref, length), SIMD_ED.cpp:147 */
+        for (int l = 1; l < lanes - 1; l++) { /* calculate_masks, SIMD_ED.cpp:180-212 */
+            const int s = abs(l - mid);
+            const v256 x0 = l > mid ? avx_shr(a0, s) : a0, x1 = l > mid ? avx_shr(a1, s) : a1;
+            const v256 y0 = l < mid ? avx_shr(b0, s) : b0, y1 = l < mid ? avx_shr(b1, s) : b1;
+            hm[l] = v_or(v_xor(x0, y0), v_xor(x1, y1));
+        }
+        int ok = 0, reached = 0;
+        if (shd_enable) { /* bit_vec_filter_avx(hamming_masks + 1, buffer_length, ED_t): SHD.cpp:324-372, S3 */
+            const v256 lm = low_ones(len >= 256 ? 256 : len);
+            v256 diff = low_ones(256);
+            for (int l = 1; l < lanes - 1; l++) {
+                const int s = abs(l - mid);
+                const v256 tm = v_and(s ? not_low_ones(s) : low_ones(255), lm);
+                diff = v_and(diff, v_and(hm[l], tm));
+            }
+            if (popcount_shd(diff) > ed_t) { /* SIMD_ED.cpp:270-273: rejected, nothing else changes */
+                pass[i] = 0, ed[i] = -1;
+                if (ed_raw) ed_raw[i] = conv;
+                continue;
+            }
+        }
+        for (int l = 0; l < lanes; l++)
+            for (int e = 0; e <= ed_t; e++) end[l][e] = -2; /* entries never written hold init_levenshtein's -2 */
+        end[mid][0] = count_id(hm[mid], 0, len);          /* SIMD_ED.cpp:277-299 */
+        if (end[mid][0] == len) {
+            fe = 0, fd = 0; /* returns with ED_pass = true; converge_ED is NOT rewritten (S2) */
+            pass[i] = 1, ed[i] = conv;
+            if (ed_raw) ed_raw[i] = conv;
+            continue;
+        }
+        for (int e = 1; e <= ed_t && !reached; e++) { /* SIMD_ED.cpp:301-346 */
+            for (int l = 1; l < lanes - 1; l++) {
+                if (abs(l - mid) > e) continue; /* cur_ED[l] == e */
+                const int top = l >= mid, bot = l <= mid;
+                int st = end[l][e - 1] + 1;
+                if (end[l - 1][e - 1] + top > st) st = end[l - 1][e - 1] + top;
+                if (end[l + 1][e - 1] + bot > st) st = end[l + 1][e - 1] + bot;
+                end[l][e] = st + count_id(hm[l], st, len);
+                if (end[l][e] == len) {
+                    fe = e, fd = abs(l - mid), reached = 1;
+                    break;
+                }
+            }
+        }
+        (void)reached;
+        conv = fe + fd; /* SIMD_ED.cpp:348-351 — with stale fe/fd when the end was never reached (S2) */
+        ok = conv <= ed_t;
+        pass[i] = (uint8_t)ok, ed[i] = ok ? conv : -1;
+        if (ed_raw) ed_raw[i] = conv;
+    }
+    return 0;
+}

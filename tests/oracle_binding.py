@@ -9,6 +9,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "libasm_oracle.so")
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libasm_ref.so")
+REF_SIMD_SO = os.path.join(ROOT, "oracle", "_ref", "libasm_ref_simd.so")
+# state the reference harness pins before a batch (its warm-up pair): final_ED, lane distance, converge_ED
+SIMD_WARM_STATE = (1, 1, 2)
 CIGAR_STRIDE = 768
 DEFAULT_PROBS = (0.80, 0.20 / 3, 0.40 / 3)
 
@@ -45,6 +48,8 @@ class Oracle:
         lib.orc_nw_cigar_batch.argtypes = b5 + [_i] * 3 + [_vp, _vp, _i]
         lib.orc_coverage_batch.argtypes = b5 + [_vp, _i, _i, _vp, _i, _i, _vp]
         lib.orc_set_threads.argtypes = [_i]
+        lib.orc_simd_ed_batch.argtypes = b5 + [_i] * 3 + [_vp] * 4
+        lib.orc_shd_batch.argtypes = b5 + [_i, _vp]
 
     def set_threads(self, n):
         return self.lib.orc_set_threads(n)
@@ -98,6 +103,24 @@ class Oracle:
         assert self.lib.orc_nw_cigar_batch(*args, x, o, e, pen.ctypes.data, cg.ctypes.data, CIGAR_STRIDE) == 0
         return pen, _cigars(cg, hb.n, CIGAR_STRIDE)
 
+    def simd_ed(self, hb, ed_t=3, shd=True, mode=0, state=SIMD_WARM_STATE):
+        """(ed, ed_raw, pass): ed = converge_ED when the pair passes else -1; ed_raw = get_ED() whatever the verdict."""
+        keep, args = _batch_args(hb)
+        ed = np.zeros(hb.n, np.int32)
+        raw = np.zeros(hb.n, np.int32)
+        ps = np.zeros(hb.n, np.uint8)
+        st = np.array(state, np.int32)
+        rc = self.lib.orc_simd_ed_batch(*args, ed_t, 1 if shd else 0, mode, st.ctypes.data, ed.ctypes.data,
+                                        raw.ctypes.data, ps.ctypes.data)
+        assert rc == 0, rc
+        return ed, raw, ps
+
+    def shd(self, hb, max_error=3):
+        keep, args = _batch_args(hb)
+        ps = np.zeros(hb.n, np.int32)
+        assert self.lib.orc_shd_batch(*args, max_error, ps.ctypes.data) == 0
+        return ps
+
     def coverage(self, hb, cigars1, thr1, cigars2, thr2):
         keep, args = _batch_args(hb)
 
@@ -113,6 +136,30 @@ class Oracle:
         assert self.lib.orc_coverage_batch(*args, b1.ctypes.data, CIGAR_STRIDE, thr1, b2.ctypes.data, CIGAR_STRIDE,
                                            thr2, out.ctypes.data) == 0
         return out
+
+
+class ReferenceSimd:
+    """The real SIMD_ED / SHD sources compiled in place — this container only (the built .so travels to the GPU box)."""
+
+    def __init__(self, lib):
+        self.lib = lib
+        b5 = [_i64, _vp, _vp, _vp, _vp]
+        lib.ref_simd_ed_batch.argtypes = b5 + [_i, _i, _vp, _vp]
+        lib.ref_shd_batch.argtypes = b5 + [_i, _vp]
+
+    def simd_ed(self, hb, ed_t=3, shd=True):
+        """(get_ED() raw, check_pass()) per pair, run in batch order after the harness's warm-up pair."""
+        keep, args = _batch_args(hb)
+        ed = np.zeros(hb.n, np.int32)
+        ps = np.zeros(hb.n, np.uint8)
+        assert self.lib.ref_simd_ed_batch(*args, ed_t, 1 if shd else 0, ed.ctypes.data, ps.ctypes.data) == 0
+        return ed, ps
+
+    def shd(self, hb, max_error=3):
+        keep, args = _batch_args(hb)
+        ps = np.zeros(hb.n, np.int32)
+        assert self.lib.ref_shd_batch(*args, max_error, ps.ctypes.data) == 0
+        return ps
 
 
 class Reference:
@@ -169,3 +216,11 @@ def have_reference():
 
 def load_reference():
     return Reference(ctypes.CDLL(REF_SO))
+
+
+def have_reference_simd():
+    return os.path.exists(REF_SIMD_SO)
+
+
+def load_reference_simd():
+    return ReferenceSimd(ctypes.CDLL(REF_SIMD_SO))

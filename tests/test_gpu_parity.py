@@ -398,3 +398,87 @@ def test_pymatch_named_classes(asm, oracle):
     hb = asm.generate_pairs(cfg, 0, 500)
     pairs = [hb.pair(i) for i in range(hb.n)]
     assert np.array_equal(pm.batch_edit_distances(pm.GASMA, pairs, k=3), oracle.greedy(hb, k=3, mode=1))
+
+
+# ---- filtering stage: bit-parallel LEAP (SIMD_ED) and SHD -------------------------------------------------
+@pytest.mark.parametrize("wl,n", [("C1", 6000), ("C2", 20000), ("C4", 6000), ("C5", 12000)])
+@pytest.mark.parametrize("ed_t,shd", [(1, True), (2, False), (3, True), (3, False), (5, True), (8, False), (10, True),
+                                       (16, True), (20, False)])
+def test_simd_ed_filter_matches_oracle(asm, engine, oracle, wl, n, ed_t, shd):
+    """SIMD_ED (Levenshtein, ED_GLOBAL) per pair: register-resident lanes (T <= 8) and the run-time-T kernel, with and
+    without the SHD pre-filter, in sequential mode (verdict state carried in batch order from the reference harness's
+    warm-up state) and in clean mode."""
+    from tests.oracle_binding import SIMD_WARM_STATE
+    cfg, _, _ = asm.workload(wl)
+    hb = asm.generate_pairs(cfg, 41, n)
+    batch = engine.upload(hb, asm.GREEDY_CLEAN)
+    for mode in (asm.FILTER_SEQUENTIAL, asm.FILTER_CLEAN):
+        want, _, want_pass = oracle.simd_ed(hb, ed_t, shd, mode, SIMD_WARM_STATE)
+        got = engine.simd_ed(batch, ed_t, shd, mode, SIMD_WARM_STATE)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (wl, ed_t, shd, mode, bad[:5], got[bad[:5]], want[bad[:5]])
+        assert ((got >= 0) == (want_pass == 1)).all()
+
+
+@pytest.mark.parametrize("max_error", [0, 1, 3, 5, 9, 16])
+def test_shd_filter_matches_oracle(asm, engine, oracle, max_error):
+    for wl, n in (("C1", 5000), ("C2", 20000), ("C5", 12000)):
+        cfg, _, _ = asm.workload(wl)
+        hb = asm.generate_pairs(cfg, 43, n)
+        batch = engine.upload(hb, asm.GREEDY_CLEAN)
+        got, want = engine.shd_filter(batch, max_error), oracle.shd(hb, max_error)
+        assert (got == want).all(), (wl, max_error, int((got != want).sum()))
+
+
+def test_filters_on_ragged_and_dirty_input(asm, engine, oracle):
+    """Empty strings, lengths around 64/128/256 (the 128-bit halves of S1), reads longer than 256 (cut at _MAX_LENGTH_),
+    references shorter and longer than the read, and bytes outside ACGT."""
+    from tests.oracle_binding import SIMD_WARM_STATE
+    hb = random_ragged_batch(asm, 47, 4000, 0, 300)
+    rng = np.random.default_rng(5)
+    reads = hb.reads.copy()
+    hits = rng.random(reads.size) < 0.01
+    reads[hits] = rng.choice(np.frombuffer(b"NnacgtRY-*", np.uint8), int(hits.sum()))
+    hb = asm.HostBatch(reads, hb.read_off, hb.refs, hb.ref_off)
+    batch = engine.upload(hb, asm.GREEDY_CLEAN)
+    for ed_t, shd in ((3, True), (7, False), (12, True)):
+        for mode in (asm.FILTER_SEQUENTIAL, asm.FILTER_CLEAN):
+            want, _, _ = oracle.simd_ed(hb, ed_t, shd, mode, SIMD_WARM_STATE)
+            got = engine.simd_ed(batch, ed_t, shd, mode, SIMD_WARM_STATE)
+            assert (got == want).all(), (ed_t, shd, mode, int((got != want).sum()))
+    for me in (2, 6):
+        assert (engine.shd_filter(batch, me) == oracle.shd(hb, me)).all()
+
+
+def test_filter_argument_errors(asm, engine):
+    cfg, _, _ = asm.workload("C1")
+    batch = engine.generate(cfg, 0, 64)
+    d = engine.malloc(4 * 64)
+    for args in ((0, True), (33, False), (17, True)):
+        with pytest.raises(asm.AsmError):
+            engine.simd_ed_async(batch, args[0], d, args[1])
+    with pytest.raises(asm.AsmError):
+        engine.shd_filter_async(batch, 17, d)
+    with pytest.raises(asm.AsmError):
+        engine.simd_ed_async(batch, 3, d, True, 7)
+    engine.free(d)
+
+
+def test_filters_against_the_real_reference(asm, engine):
+    """The compiled SIMD_ED / SHD sources (oracle/_ref/libasm_ref_simd.so, built in the dev container, travels with the
+    snapshot): verdicts and get_ED() of passing pairs, run in batch order after the harness's warm-up pair."""
+    from tests import oracle_binding as ob
+    if not ob.have_reference_simd():
+        pytest.skip("oracle/_ref/libasm_ref_simd.so not built")
+    ref = ob.load_reference_simd()
+    for wl, n in (("C2", 20000), ("C5", 10000)):
+        cfg, _, _ = asm.workload(wl)
+        hb = asm.generate_pairs(cfg, 53, n)
+        batch = engine.upload(hb, asm.GREEDY_CLEAN)
+        for ed_t, shd in ((3, True), (5, False), (12, True)):
+            r_ed, r_pass = ref.simd_ed(hb, ed_t, shd)
+            got = engine.simd_ed(batch, ed_t, shd, asm.FILTER_SEQUENTIAL, ob.SIMD_WARM_STATE)
+            assert ((got >= 0) == (r_pass == 1)).all(), (wl, ed_t, shd)
+            assert (got[r_pass == 1] == r_ed[r_pass == 1]).all(), (wl, ed_t, shd)
+        for me in (3, 8):
+            assert (engine.shd_filter(batch, me) == ref.shd(hb, me)).all(), (wl, me)

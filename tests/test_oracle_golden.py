@@ -102,3 +102,42 @@ def test_coverage_metric_and_nw_cigar(asm, oracle):
     cov = oracle.coverage(hb, gcig, 1, ncig, 3)
     assert 0.85 < cov.mean() <= 1.0  # README.md:36 reports 94.2 % with parasail's traceback (unpinned tie-break)
     assert oracle.coverage(hb, ncig, 1, ncig, 3).all()  # an alignment covers itself
+
+
+# ---- filtering stage: bit-parallel LEAP (SIMD_ED) and SHD, goldens of tests/golden/make_golden_filter.py ----
+with open(os.path.join(GOLD, "filter_index.json")) as fh:
+    FILTER_INDEX = json.load(fh)
+
+
+@pytest.mark.parametrize("name", sorted(FILTER_INDEX["cases"]))
+def test_filter_oracle_matches_reference_goldens(asm, oracle, name):
+    meta = FILTER_INDEX["cases"][name]
+    cfg, _, _ = asm.workload(meta["workload"])
+    hb = asm.generate_pairs(cfg, meta["first"], meta["n"])
+    assert _inputs_sha(hb) == meta["inputs_sha256"], "generator output changed: regenerate the goldens deliberately"
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    state = tuple(FILTER_INDEX["warm_state"])
+    for t, shd in FILTER_INDEX["simd_settings"]:
+        ed, raw, ps = oracle.simd_ed(hb, t, bool(shd), 0, state)
+        assert np.array_equal(ps, gold[f"pass_t{t}_shd{shd}"]), (name, t, shd, "check_pass")
+        assert np.array_equal(raw, gold[f"ed_t{t}_shd{shd}"]), (name, t, shd, "get_ED")
+        assert np.array_equal(ed, np.where(ps == 1, raw, -1))
+    for me in FILTER_INDEX["shd_errors"]:
+        assert np.array_equal(oracle.shd(hb, me), gold[f"shd_e{me}"]), (name, me)
+
+
+def test_filter_clean_mode_hand_cases(asm, oracle):
+    """Judged alone (clean mode): exact pair 0; one substitution inside 1; a substitution in the LAST character 2, because
+    lane mid-1 is swept before the main lane and reaches the end through its diagonal neighbour (SIMD_ED.cpp:303-340);
+    unrelated strings fail; a passing verdict is always <= T."""
+    base = "ACGTTGCAAGCTTAGCCATGGATCCTAGGTACCGATATCGGCATGCAAGT"
+    sub = base[:20] + ("A" if base[20] != "A" else "C") + base[21:]
+    last = base[:-1] + ("A" if base[-1] != "A" else "C")
+    other = "T" * len(base)
+    hb = asm.HostBatch.from_strings([(base, base), (sub, base), (last, base), (other, base), ("", "")])
+    ed, _, ps = oracle.simd_ed(hb, 3, False, 1, (0, 0, 0))
+    assert ed.tolist() == [0, 1, 2, -1, 0] and ps.tolist() == [1, 1, 1, 0, 1]
+    cfg, _, _ = asm.workload("C2")
+    big = asm.generate_pairs(cfg, 7, 3000)
+    ed, _, ps = oracle.simd_ed(big, 6, False, 1, (0, 0, 0))
+    assert ((ed >= 0) == (ps == 1)).all() and (ed <= 6).all() and 0.02 < ps.mean() < 0.9

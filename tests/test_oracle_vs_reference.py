@@ -59,3 +59,37 @@ def test_stale_tail_model(asm, oracle, ref):
     fwd_cost, rev_cost = ref.greedy(hb2, 3, mode=0), ref.greedy(rev, 3, mode=0)[::-1]
     assert (fwd_cost != rev_cost).sum() > 0
     assert np.array_equal(ref.greedy(hb2, 3, mode=1), ref.greedy(rev, 3, mode=1)[::-1])  # clean mode is order free
+
+
+# ---- filtering stage: the real SIMD_ED / SHD sources (oracle/_ref/libasm_ref_simd.so) ----
+@pytest.mark.skipif(not oracle_binding.have_reference_simd(), reason="oracle/_ref/libasm_ref_simd.so not built")
+@pytest.mark.parametrize("wl,n", [("C1", 8000), ("C2", 20000), ("C4", 8000), ("C5", 10000)])
+def test_filter_oracle_equals_reference(asm, oracle, wl, n):
+    ref = oracle_binding.load_reference_simd()
+    cfg, _, _ = asm.workload(wl)
+    hb = asm.generate_pairs(cfg, 271828, n)
+    for t in (1, 2, 3, 4, 6, 9, 13, 16, 21, 32):
+        for shd in ((False, True) if t <= 16 else (False,)):
+            r_ed, r_ps = ref.simd_ed(hb, t, shd)
+            _, o_raw, o_ps = oracle.simd_ed(hb, t, shd, 0, oracle_binding.SIMD_WARM_STATE)
+            assert np.array_equal(r_ps, o_ps) and np.array_equal(r_ed, o_raw), (wl, t, shd)
+    for me in (0, 1, 2, 4, 7, 11, 16):
+        assert np.array_equal(ref.shd(hb, me), oracle.shd(hb, me)), (wl, me)
+
+
+@pytest.mark.skipif(not oracle_binding.have_reference_simd(), reason="oracle/_ref/libasm_ref_simd.so not built")
+def test_filter_oracle_equals_reference_on_ragged_and_dirty_input(asm, oracle):
+    from tests.util import random_ragged_batch
+    ref = oracle_binding.load_reference_simd()
+    hb = random_ragged_batch(asm, 61, 6000, 0, 300)
+    rng = np.random.default_rng(9)
+    reads = hb.reads.copy()
+    hits = rng.random(reads.size) < 0.01
+    reads[hits] = rng.choice(np.frombuffer(b"NnacgtRY-*", np.uint8), int(hits.sum()))
+    hb = asm.HostBatch(reads, hb.read_off, hb.refs, hb.ref_off)
+    for t, shd in ((3, True), (3, False), (8, True), (16, True), (25, False)):
+        r_ed, r_ps = ref.simd_ed(hb, t, shd)
+        _, o_raw, o_ps = oracle.simd_ed(hb, t, shd, 0, oracle_binding.SIMD_WARM_STATE)
+        assert np.array_equal(r_ps, o_ps) and np.array_equal(r_ed, o_raw), (t, shd)
+    for me in (1, 5, 16):
+        assert np.array_equal(ref.shd(hb, me), oracle.shd(hb, me)), me
