@@ -66,12 +66,18 @@ ASM_DEV int simd_extend(const VW<W64>& mask, int st, int len) {
     return r < len ? r : len;
 }
 
-// popcount_SHD_avx (popcount.cpp:44-76,78-110): per nibble, the number of runs of ones
+// popcount_SHD_avx (popcount.cpp:44-76,78-110): a table lookup per nibble that is the number of runs of ones in the nibble,
+// except that 0110 counts 2
 template <int W64>
 ASM_DEV int shd_popcount(const VW<W64>& v) {
     int s = 0;
 #pragma unroll
-    for (int q = 0; q < W64; q++) s += __builtin_popcountll(v.w[q] & ~((v.w[q] << 1) & 0xeeeeeeeeeeeeeeeeull));
+    for (int q = 0; q < W64; q++) {
+        const u64 w = v.w[q];
+        const u64 x = w ^ 0x6666666666666666ull; /* a nibble of x is zero where w's is 0110 */
+        const u64 is6 = ~(x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x1111111111111111ull;
+        s += __builtin_popcountll(w & ~((w << 1) & 0xeeeeeeeeeeeeeeeeull)) + __builtin_popcountll(is6);
+    }
     return s;
 }
 
