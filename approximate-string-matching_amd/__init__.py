@@ -390,14 +390,15 @@ class Engine:
 
     # ---- filtering stage: bit-parallel LEAP (SIMD_ED) and SHD (LEAP_SIMD/main.cpp:95-101,186-195) ----
     def simd_ed_async(self, batch: DeviceBatch, ed_threshold: int, d_ed: int, shd: bool = True, mode: int = FILTER_CLEAN,
-                      state: Optional[Sequence[int]] = None) -> None:
+                      state: Optional[Sequence[int]] = None) -> Optional[Tuple[int, ...]]:
         """SIMD_ED::init_levenshtein(ed_threshold, ED_GLOBAL, shd) + load_reads/calculate_masks/reset/run per pair:
         d_ed[i] = get_ED() when check_pass() else -1.  state = (final_ED, lane distance, converge_ED) carried into the
-        first pair in FILTER_SEQUENTIAL mode."""
+        first pair in FILTER_SEQUENTIAL mode; returns the state after the last pair (for the next chunk of the same file)."""
         st = None
         if state is not None:
             st = (ctypes.c_int32 * 3)(*[int(v) for v in state])
         self._chk(self.lib.asm_simd_ed_batch_async(self.h, batch.ptr, int(ed_threshold), 1 if shd else 0, int(mode), st, d_ed))
+        return tuple(st) if st is not None else None
 
     def simd_ed(self, batch: DeviceBatch, ed_threshold: int, shd: bool = True, mode: int = FILTER_CLEAN,
                 state: Optional[Sequence[int]] = None) -> np.ndarray:

@@ -1045,7 +1045,7 @@ int asm_align_batch(asm_handle* h, int aligner, int64_t n, const char* reads, co
 }
 
 int asm_simd_ed_batch_async(asm_handle* h, const asm_batch* b, int ed_threshold, int shd_enable, int mode,
-                            const int32_t* state, int32_t* d_ed) {
+                            int32_t* state, int32_t* d_ed) {
     if (!h || !b || !d_ed) return fail(h, ASM_EINVAL, "asm_simd_ed_batch_async: NULL argument");
     if (ed_threshold < 1 || ed_threshold > ASM_FILTER_MAX_T)
         return fail(h, ASM_EINVAL, "asm_simd_ed_batch_async: ED threshold must be in [1, 32]");
@@ -1076,6 +1076,7 @@ int asm_simd_ed_batch_async(asm_handle* h, const asm_batch* b, int ed_threshold,
     /* sequential: resolve the verdict chain in batch order with two last-setter scans */
     const int init_fe = state ? state[0] : 0, init_fd = state ? state[1] : 0, init_conv = state ? state[2] : 0;
     int32_t *d_a = nullptr, *d_b = nullptr;
+    int32_t last_setter = -1, last_conv = -1;
     void* d_tmp = nullptr;
     size_t tmp_bytes = 0;
     do {
@@ -1090,12 +1091,18 @@ int asm_simd_ed_batch_async(asm_handle* h, const asm_batch* b, int ed_threshold,
         TRY(hipMalloc(&d_tmp, tmp_bytes + 16));
         hipLaunchKernelGGL(simd_ed_setter_kernel, g, t, 0, h->stream, (const int32_t*)d_ed, n, d_a);
         TRY(hipcub::DeviceScan::InclusiveScan(d_tmp, tmp_bytes, d_a, d_b, LastSetter(), (int)n, h->stream));
+        TRY(hipMemcpyAsync(&last_setter, d_b + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
         hipLaunchKernelGGL(simd_ed_converge_kernel, g, t, 0, h->stream, (const int32_t*)d_ed, (const int32_t*)d_b, n, init_fe,
                            init_fd, d_a);
         TRY(hipcub::DeviceScan::InclusiveScan(d_tmp, tmp_bytes, d_a, d_b, LastSetter(), (int)n, h->stream));
+        TRY(hipMemcpyAsync(&last_conv, d_b + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
         hipLaunchKernelGGL(simd_ed_verdict_kernel, g, t, 0, h->stream, d_ed, (const int32_t*)d_b, n, ed_threshold, init_conv);
         TRY(hipGetLastError());
         TRY(hipStreamSynchronize(h->stream)); /* the scratch below is freed on return */
+        if (state) { /* the state the next batch of the same stream of pairs starts from */
+            if (last_setter >= 0) state[0] = last_setter & 0xff, state[1] = last_setter >> 8;
+            if (last_conv >= 0) state[2] = last_conv;
+        }
 #undef TRY
     } while (0);
     if (d_a) (void)hipFree(d_a);

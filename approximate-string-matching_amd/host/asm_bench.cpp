@@ -2,6 +2,8 @@
 // generate (or read) a ">read\n<ref\n" file, run NW + LEAP + Greedy over it, print the results block.
 //   asm-bench [--file path | --n N --len L --err E --seed S] [--k K --x X --o O --e E] [--mode sequential|clean]
 //             [--answers path]
+//   asm-bench --leap-simd ERROR [--shd 0|1] [--batch-run N] < pairs      the LEAP_SIMD stdin filter driver
+//                                                                        (GASMA/benchmark/LEAP_SIMD/main.cpp:52-101)
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -11,6 +13,8 @@
 int main(int argc, char** argv) {
     using namespace asm_amd;
     std::string file, answers, mode = "sequential";
+    int leap_simd = -1, shd = 1;
+    long batch_run = 1000000;
     int n = 1000000, len = 100, k = 3, x = 1, o = 1, e = 1;
     float err = 0.10f;
     uint64_t seed = 2;
@@ -27,12 +31,16 @@ int main(int argc, char** argv) {
         else if (arg("--o")) o = atoi(argv[++i]);
         else if (arg("--e")) e = atoi(argv[++i]);
         else if (arg("--mode")) mode = argv[++i];
+        else if (arg("--leap-simd")) leap_simd = atoi(argv[++i]);
+        else if (arg("--shd")) shd = atoi(argv[++i]);
+        else if (arg("--batch-run")) batch_run = atol(argv[++i]);
         else {
             fprintf(stderr, "unknown argument %s\n", argv[i]);
             return 2;
         }
     }
     try {
+        if (leap_simd >= 0) return leap_simd_filter(stdin, leap_simd, shd != 0, batch_run);
         if (file.empty()) {
             Dataset dataset(n, len, err, 0.96f, true, seed);  // benchmark.cpp:19
             file = dataset.output();

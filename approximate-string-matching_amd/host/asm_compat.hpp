@@ -4,6 +4,8 @@
 //   LV                init/load_reads/reset/run/check_pass/get_ED   GASMA/benchmark/LEAP_SIMD/LV_BAG.h:40-54
 //   benchmark         read_string_file/read_answer_file/run/print   GASMA/benchmark/benchmark_utils.h:263-402
 //   Dataset           output()                                       GASMA/benchmark/benchmark_dataset.h:189-253
+//   SIMD_ED           init_levenshtein/load_reads/calculate_masks/reset/run/check_pass/get_ED   LEAP_SIMD/SIMD_ED.h:47-70
+//   leap_simd_filter  the stdin filter driver                        GASMA/benchmark/LEAP_SIMD/main.cpp:31-300
 // Same names, argument meaning and (absence of an) error channel as the reference, except that failures of
 // the device library throw std::runtime_error instead of being ignored.  Everything computes on the GPU through
 // libasm_mi355x.so; there is no CPU path.  The per-pair classes launch one-pair batches (kept for interface
@@ -90,6 +92,103 @@ public:
     bool check_pass() const { return ed_ >= 0; }
     int get_ED() const { return ed_; }
 };
+
+// Bit-parallel LEAP in Levenshtein mode (LEAP_SIMD/SIMD_ED.h:47-70).  Like the reference object it keeps its verdict
+// state from pair to pair (SIMD_ED.cpp:258-268,348-351); unlike the reference's, the state starts defined (zeros).
+class SIMD_ED {
+    int ed_t_ = 0;
+    bool shd_ = true;
+    int32_t state_[3] = {0, 0, 0};
+    std::string read_, ref_;
+    int ed_ = -1;
+
+public:
+    void init_levenshtein(int ED_threshold, ED_modes mode = ED_GLOBAL, bool SHD_enable = true) {
+        if (mode != ED_GLOBAL) throw std::runtime_error("SIMD_ED::init_levenshtein: the accelerated path is ED_GLOBAL (main.cpp:97)");
+        ed_t_ = ED_threshold, shd_ = SHD_enable;
+    }
+    void load_reads(char* read, char* ref, int length) {  // strncpy semantics: NUL-terminated, at most `length` characters
+        read_.assign(read, strnlen(read, (size_t)length));
+        ref_.assign(ref, strnlen(ref, (size_t)length));
+        read_.resize((size_t)length, '\0');  // buffer_length = length whatever the strings hold (SIMD_ED.cpp:140-151)
+    }
+    void calculate_masks() {}
+    void reset() { ed_ = -1; }
+    void run() {
+        asm_handle* h = shared_handle();
+        uint32_t ro[2] = {0u, (uint32_t)read_.size()}, fo[2] = {0u, (uint32_t)ref_.size()};
+        asm_batch* b = nullptr;
+        void* d = nullptr;
+        int32_t out = -1;
+        check(h, asm_batch_upload(h, 1, read_.data(), ro, ref_.data(), fo, ASM_GREEDY_CLEAN, &b));
+        check(h, asm_device_malloc(h, sizeof(int32_t), &d));
+        const int rc = asm_simd_ed_batch_async(h, b, ed_t_, shd_ ? 1 : 0, ASM_FILTER_SEQUENTIAL, state_, (int32_t*)d);
+        if (rc == ASM_OK) check(h, asm_memcpy_d2h(h, &out, d, sizeof(int32_t)));
+        asm_device_free(h, d);
+        asm_batch_free(h, b);
+        check(h, rc);
+        ed_ = out;
+    }
+    bool check_pass() const { return ed_ >= 0; }
+    int get_ED() const { return ed_; }
+};
+
+// The stdin filter driver (LEAP_SIMD/main.cpp:31-300): pairs of lines (read, reference) until "end_of_file", processed in
+// chunks of BATCH_RUN pairs — each chunk one GPU batch, the verdict state chained from chunk to chunk — then
+// passNum / totalNum / total_time (GPU time of the filter calls instead of CPU user time).
+inline int leap_simd_filter(FILE* in, int error, bool use_shd, int64_t batch_run = 1000000) {
+    asm_handle* h = shared_handle();
+    int32_t state[3] = {0, 0, 0};
+    unsigned long long pass_num = 0, total_num = 0;
+    double seconds = 0;
+    char* line = nullptr;
+    size_t cap = 0;
+    bool stop = false;
+    void* tm = nullptr;
+    check(h, asm_timer_create(h, &tm));
+    while (!stop) {
+        std::vector<char> reads, refs;
+        std::vector<uint32_t> ro{0}, fo{0};
+        for (int64_t i = 0; i < batch_run; i++) {
+            ssize_t got = getline(&line, &cap, in);
+            if (got <= 0) { stop = true; break; }
+            if (line[got - 1] == '\n') got--;
+            if (got == 11 && !strncmp(line, "end_of_file", 11)) { stop = true; break; }
+            reads.insert(reads.end(), line, line + got);
+            ro.push_back((uint32_t)reads.size());
+            got = getline(&line, &cap, in);
+            if (got < 0) got = 0;
+            if (got > 0 && line[got - 1] == '\n') got--;
+            refs.insert(refs.end(), line, line + got);
+            fo.push_back((uint32_t)refs.size());
+        }
+        const int64_t n = (int64_t)ro.size() - 1;
+        if (n == 0) break;
+        asm_batch* b = nullptr;
+        void* d = nullptr;
+        float ms = 0;
+        check(h, asm_batch_upload(h, n, reads.data(), ro.data(), refs.data(), fo.data(), ASM_GREEDY_CLEAN, &b));
+        check(h, asm_device_malloc(h, sizeof(int32_t) * (size_t)n, &d));
+        check(h, asm_timer_start(h, tm));
+        check(h, asm_simd_ed_batch_async(h, b, error, use_shd ? 1 : 0, ASM_FILTER_SEQUENTIAL, state, (int32_t*)d));
+        check(h, asm_timer_stop(h, tm));
+        check(h, asm_timer_elapsed_ms(h, tm, &ms));
+        seconds += ms * 1e-3;
+        std::vector<int32_t> ed((size_t)n);
+        check(h, asm_memcpy_d2h(h, ed.data(), d, sizeof(int32_t) * (size_t)n));
+        for (int32_t v : ed) pass_num += v >= 0;
+        total_num += (unsigned long long)n;
+        asm_device_free(h, d);
+        asm_batch_free(h, b);
+    }
+    free(line);
+    asm_timer_destroy(h, tm);
+    fprintf(stderr, "end_of_file\n");
+    printf("passNum:\t%llu\n", pass_num);
+    printf("totalNum:\t%llu\n", total_num);
+    printf("total_time: %f\n", seconds);
+    return 0;
+}
 
 // Seeded counterpart of `Dataset` (writes the same ">read\n<ref\n" file; the seed replaces time()).
 class Dataset {

@@ -162,13 +162,14 @@ int asm_align_batch(asm_handle* h, int aligner, int64_t n, const char* reads, co
  * mode: the reference keeps its verdict state from pair to pair (a pair that never reaches the end inherits the verdict
  * of the last pair that did; an exact pair reports the previous converge_ED) — ASM_FILTER_SEQUENTIAL reproduces that in
  * batch order, starting from state = {final_ED, lane distance, converge_ED} (NULL: zeros; the reference leaves them
- * uninitialised), ASM_FILTER_CLEAN judges every pair on its own (never reached: -1; exact: 0).
+ * uninitialised) and writes the state after the last pair back into it, so that a file processed in chunks (BATCH_RUN,
+ * main.cpp:20) chains exactly; ASM_FILTER_CLEAN judges every pair on its own (never reached: -1; exact: 0).
  * ed_threshold in [1, 32]; with shd_enable at most 16 (MAX_ERROR_AVX, LEAP_SIMD/mask.h:21).  Enqueue only in clean
  * mode; sequential mode returns after its scans have run. */
 #define ASM_FILTER_SEQUENTIAL 0
 #define ASM_FILTER_CLEAN 1
 int asm_simd_ed_batch_async(asm_handle* h, const asm_batch* b, int ed_threshold, int shd_enable, int mode,
-                            const int32_t* state, int32_t* d_ed);
+                            int32_t* state, int32_t* d_ed);
 /* bit_vec_filter_avx(read planes, ref planes, min(m, 256), max_error) (LEAP_SIMD/SHD.h:17-18, SHD.cpp:241-322):
  * d_pass[i] = 1 when the pair survives the shifted-Hamming-distance filter, 0 when it is rejected.  max_error in
  * [0, 16].  Enqueue only. */

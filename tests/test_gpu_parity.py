@@ -482,3 +482,29 @@ def test_filters_against_the_real_reference(asm, engine):
             assert (got[r_pass == 1] == r_ed[r_pass == 1]).all(), (wl, ed_t, shd)
         for me in (3, 8):
             assert (engine.shd_filter(batch, me) == ref.shd(hb, me)).all(), (wl, me)
+
+
+def test_filter_state_chains_across_chunks_and_stdin_driver(asm, engine, oracle, tmp_path):
+    """A file filtered in chunks (BATCH_RUN, LEAP_SIMD/main.cpp:20,104-140) with the state handed from chunk to chunk gives
+    the verdicts of one pass over the whole file; asm-bench --leap-simd is that driver (passNum / totalNum lines)."""
+    import os
+    import subprocess
+
+    cfg, _, _ = asm.workload("C5")
+    hb = asm.generate_pairs(cfg, 59, 9000)
+    for ed_t, shd in ((3, True), (6, False)):
+        want, _, ps = oracle.simd_ed(hb, ed_t, shd, 0, (0, 0, 0))
+        state, got = (0, 0, 0), []
+        for lo in range(0, hb.n, 2500):
+            part = hb.slice(lo, min(hb.n, lo + 2500))
+            b = engine.upload(part, asm.GREEDY_CLEAN)
+            d = engine.malloc(4 * part.n)
+            state = engine.simd_ed_async(b, ed_t, d, shd, asm.FILTER_SEQUENTIAL, state)
+            got.append(engine.to_host(d, part.n))
+            engine.free(d)
+        assert (np.concatenate(got) == want).all(), (ed_t, shd)
+        text = "".join("%s\n%s\n" % hb.pair(i) for i in range(hb.n)) + "end_of_file\n"
+        exe = os.path.join(os.path.dirname(asm.LIB_PATH), "asm-bench")
+        out = subprocess.run([exe, "--leap-simd", str(ed_t), "--shd", "1" if shd else "0", "--batch-run", "2000"],
+                             input=text, capture_output=True, text=True, check=True).stdout.splitlines()
+        assert out[0] == "passNum:\t%d" % int(ps.sum()) and out[1] == "totalNum:\t%d" % hb.n, out[:3]
