@@ -109,8 +109,11 @@ static hipError_t launch_persistent(asm_handle* h, Kern kern, int64_t n, Args...
 
 template <int K>
 static hipError_t launch_greedy(asm_handle* h, const asm_bucket& b, const GreedyArgs& ga, OutMap out, CigarSink cig) {
+    if (h->persist && ga.x == 1 && ga.o == 1 && ga.e == 1)
+        return launch_persistent(h, greedy_persist_kernel<K, true>, b.n, (const uint4*)b.planes, (const uint32_t*)b.lens,
+                                 (long)b.n, b.w4, ga, out, cig, h->refill_greedy);
     if (h->persist)
-        return launch_persistent(h, greedy_persist_kernel<K>, b.n, (const uint4*)b.planes, (const uint32_t*)b.lens,
+        return launch_persistent(h, greedy_persist_kernel<K, false>, b.n, (const uint4*)b.planes, (const uint32_t*)b.lens,
                                  (long)b.n, b.w4, ga, out, cig, h->refill_greedy);
     hipLaunchKernelGGL(greedy_kernel<K>, dim3(grid_for(b.n)), dim3(ASM_BLOCK), 0, h->stream, b.planes, b.lens, (long)b.n,
                        b.w4, ga, out, cig);
