@@ -115,6 +115,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void leap_wave_kernel(const uint4* __res
 // Greedy, wave per pair.  Same step structure as greedy_kernel<K> (hurdle_matrix.h:285-434,568-597); lane t of the
 // wave is band lane t - k.
 // --------------------------------------------------------------------------------------------------------
+template <bool UNIT> /* UNIT: x = o = e = 1 at compile time */
 __global__ __launch_bounds__(ASM_BLOCK) void greedy_wave_kernel(const uint4* __restrict__ planes,
                                                                 const uint32_t* __restrict__ lens, long n, int w4,
                                                                 int k, GreedyArgs args, OutMap out, CigarSink cig) {
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_wave_kernel(const uint4* __r
     const int nl = 2 * k + 1;
     const bool active = t < nl;
     const int lane = t - k;
-    const int x = args.x, o = args.o, e = args.e;
+    const int x = UNIT ? 1 : args.x, o = UNIT ? 1 : args.o, e = UNIT ? 1 : args.e;
     for (long i = wave0; i < n; i += nwaves) {
         const V128 A0 = v_from_uint4(planes[((long)0 * w4) * n + i]);
         const V128 A1 = v_from_uint4(planes[((long)1 * w4) * n + i]);
