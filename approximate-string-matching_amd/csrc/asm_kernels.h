@@ -689,10 +689,16 @@ ASM_DEV int leap_unit_pair(const uint4* __restrict__ planes, const uint32_t* __r
 #pragma unroll
     for (int j = 0; j < NL; j++) mask[j] = leap_lane_mask<W64>(A0, A1, B0, B1, VA, VB, j - K);
 
-    // generation e-1 state per lane: end, I_pos, D_pos (-2 = never reached, LV_BAG.cpp:95-101)
-    int en[NL], ip[NL], dp[NL];
+    // Generation e-1 state per lane: `end` only (-2 = never reached, LV_BAG.cpp:95-101).  With o == ext (here 1 == 1) the
+    // I and D tables carry no information of their own: I[l][e] is taken from end[l-1][e-o] when that is > I[l-1][e-ext],
+    // else from I[l-1][e-ext] (LV_BAG.cpp:166-176) — the same generation e-1 on both sides — and end[.][g] >= I[.][g]
+    // whenever I[.][g] >= 0, because a lane's start is max(end+1, I, D) (:186-201) and its end is never before its start.
+    // So I[l][e] = end[l-1][e-1] + top if that end is >= 0, else -2; likewise D from lane l+1.  And since -2 + {0,1} and
+    // -2 + 1 stay negative, start = max(end+1, end_up+top, end_dn+bot) needs no selects: it is negative exactly when all
+    // three sources are -2.
+    int en[NL];
 #pragma unroll
-    for (int j = 0; j < NL; j++) en[j] = ip[j] = dp[j] = -2;
+    for (int j = 0; j < NL; j++) en[j] = -2;
 
     int result = -1;
     // e = 0: only the main diagonal is live in ED_GLOBAL (LV_BAG.cpp:102-104,131-147)
@@ -703,26 +709,17 @@ ASM_DEV int leap_unit_pair(const uint4* __restrict__ planes, const uint32_t* __r
         if (e0 == len) result = 0;
     }
     for (int e = 1; e <= ASM_LEAP_AF_THRESHOLD && result < 0; e++) {
-        int en2[NL], ip2[NL], dp2[NL];
+        int en2[NL];
         bool pass = false;
 #pragma unroll
         for (int j = 0; j < NL; j++) {
             const int d = j - K;
             const int top = d >= 0 ? 1 : 0, bot = d <= 0 ? 1 : 0;
-            const int e_up = j > 0 ? en[j - 1] : -2, i_up = j > 0 ? ip[j - 1] : -2;
-            const int e_dn = j < NL - 1 ? en[j + 1] : -2, d_dn = j < NL - 1 ? dp[j + 1] : -2;
-            int inew = -2, dnew = -2;
-            if (e_up >= 0 && e_up > i_up)
-                inew = e_up + top; /* LV_BAG.cpp:166-167 */
-            else if (i_up >= 0)
-                inew = i_up + top; /* :172-176 */
-            if (e_dn >= 0 && e_dn > d_dn)
-                dnew = e_dn + bot; /* :179-180 */
-            else if (d_dn >= 0)
-                dnew = d_dn + bot; /* :181-182 */
-            int st = en[j] >= 0 ? en[j] + 1 : -2; /* :186-187 */
-            st = inew > st ? inew : st;           /* :193-194 */
-            st = dnew > st ? dnew : st;           /* :200-201 */
+            const int e_up = j > 0 ? en[j - 1] : -2;
+            const int e_dn = j < NL - 1 ? en[j + 1] : -2;
+            int st = en[j] + 1;                        /* :186-187 */
+            st = e_up + top > st ? e_up + top : st;    /* I_pos, :166-176,193-194 */
+            st = e_dn + bot > st ? e_dn + bot : st;    /* D_pos, :179-182,200-201 */
             int enew = -2;
             if (st >= 0) {
                 const int from = st > len ? len : st;
@@ -735,10 +732,10 @@ ASM_DEV int leap_unit_pair(const uint4* __restrict__ planes, const uint32_t* __r
                     if (conv <= ASM_LEAP_AF_THRESHOLD) pass = true;
                 }
             }
-            en2[j] = enew, ip2[j] = inew, dp2[j] = dnew;
+            en2[j] = enew;
         }
 #pragma unroll
-        for (int j = 0; j < NL; j++) en[j] = en2[j], ip[j] = ip2[j], dp[j] = dp2[j];
+        for (int j = 0; j < NL; j++) en[j] = en2[j];
         if (pass) result = e; /* final_ED (LV_BAG.cpp:228,356-358), not converge_ED */
     }
     return result;
@@ -1035,7 +1032,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void leap_unit_persist_kernel(const uint
                                                                       int refill_min) {
     constexpr int NL = 2 * K + 1;
     VW<W64> mask[NL];
-    int en[NL], ip[NL], dp[NL];
+    int en[NL]; /* `end` only: with o == ext the I/D tables are redundant (see leap_unit_pair) */
     int len = 0, e = 0, result = -1;
     long idx = -1;
     bool active = false, finished = true, exhausted = false;
@@ -1043,7 +1040,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void leap_unit_persist_kernel(const uint
     wq.init(n);
 #pragma unroll
     for (int j = 0; j < NL; j++) {
-        en[j] = ip[j] = dp[j] = -2;
+        en[j] = -2;
 #pragma unroll
         for (int q = 0; q < W64; q++) mask[j].w[q] = ~0ull;
     }
@@ -1070,7 +1067,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void leap_unit_persist_kernel(const uint
 #pragma unroll
                 for (int j = 0; j < NL; j++) {
                     mask[j] = leap_lane_mask<W64>(A0, A1, B0, B1, VA, VB, j - K);
-                    en[j] = ip[j] = dp[j] = -2;
+                    en[j] = -2;
                 }
                 // e = 0: only the main diagonal is live in ED_GLOBAL (LV_BAG.cpp:102-104,131-147)
                 int e0 = vw_next_one<W64>(mask[K], 0);
@@ -1088,26 +1085,17 @@ __global__ __launch_bounds__(ASM_BLOCK) void leap_unit_persist_kernel(const uint
         }
         if (active && !finished) {
             e++;
-            int en2[NL], ip2[NL], dp2[NL];
+            int en2[NL];
             bool pass = false;
 #pragma unroll
             for (int j = 0; j < NL; j++) {
                 const int d = j - K;
                 const int top = d >= 0 ? 1 : 0, bot = d <= 0 ? 1 : 0;
-                const int e_up = j > 0 ? en[j - 1] : -2, i_up = j > 0 ? ip[j - 1] : -2;
-                const int e_dn = j < NL - 1 ? en[j + 1] : -2, d_dn = j < NL - 1 ? dp[j + 1] : -2;
-                int inew = -2, dnew = -2;
-                if (e_up >= 0 && e_up > i_up)
-                    inew = e_up + top; /* LV_BAG.cpp:166-167 */
-                else if (i_up >= 0)
-                    inew = i_up + top; /* :172-176 */
-                if (e_dn >= 0 && e_dn > d_dn)
-                    dnew = e_dn + bot; /* :179-180 */
-                else if (d_dn >= 0)
-                    dnew = d_dn + bot; /* :181-182 */
-                int st = en[j] >= 0 ? en[j] + 1 : -2; /* :186-187 */
-                st = inew > st ? inew : st;           /* :193-194 */
-                st = dnew > st ? dnew : st;           /* :200-201 */
+                const int e_up = j > 0 ? en[j - 1] : -2;
+                const int e_dn = j < NL - 1 ? en[j + 1] : -2;
+                int st = en[j] + 1;                     /* LV_BAG.cpp:186-187 */
+                st = e_up + top > st ? e_up + top : st; /* I_pos, :166-176,193-194 */
+                st = e_dn + bot > st ? e_dn + bot : st; /* D_pos, :179-182,200-201 */
                 int enew = -2;
                 if (st >= 0) {
                     const int from = st > len ? len : st;
@@ -1119,10 +1107,10 @@ __global__ __launch_bounds__(ASM_BLOCK) void leap_unit_persist_kernel(const uint
                         if (e + diff <= ASM_LEAP_AF_THRESHOLD) pass = true;
                     }
                 }
-                en2[j] = enew, ip2[j] = inew, dp2[j] = dnew;
+                en2[j] = enew;
             }
 #pragma unroll
-            for (int j = 0; j < NL; j++) en[j] = en2[j], ip[j] = ip2[j], dp[j] = dp2[j];
+            for (int j = 0; j < NL; j++) en[j] = en2[j];
             if (pass) result = e, finished = true; /* final_ED (LV_BAG.cpp:228,356-358) */
             if (e >= ASM_LEAP_AF_THRESHOLD) finished = true;
         }

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void leap_wave_kernel(const uint4* __res
         load_planes<W64>(planes, n, w4, i, A0, A1, B0, B1);
         const VW<W64> VA = vw_low_ones<W64>(m), VB = vw_low_ones<W64>(nn);
         VW<W64> mask = leap_lane_mask<W64>(A0, A1, B0, B1, VA, VB, active ? d : 0);
-        int en = -2, ip = -2, dp = -2, result = -1;
+        int en = -2, result = -1; /* `end` only: with o == ext the I/D tables are redundant (see leap_unit_pair) */
         if (t == k) { /* e = 0: main diagonal only (LV_BAG.cpp:102-104,131-147) */
             int e0 = vw_next_one<W64>(mask, 0);
             en = e0 > len ? len : e0;
@@ -76,20 +76,10 @@ __global__ __launch_bounds__(ASM_BLOCK) void leap_wave_kernel(const uint4* __res
             result = 0;
         } else {
             for (int e = 1; e <= ASM_LEAP_AF_THRESHOLD; e++) {
-                const int e_up = wave_from_below(en, -2), i_up = wave_from_below(ip, -2);
-                const int e_dn = wave_from_above(en, -2), d_dn = wave_from_above(dp, -2);
-                int inew = -2, dnew = -2;
-                if (e_up >= 0 && e_up > i_up)
-                    inew = e_up + top; /* LV_BAG.cpp:166-167 */
-                else if (i_up >= 0)
-                    inew = i_up + top; /* :172-176 */
-                if (e_dn >= 0 && e_dn > d_dn)
-                    dnew = e_dn + bot; /* :179-180 */
-                else if (d_dn >= 0)
-                    dnew = d_dn + bot; /* :181-182 */
-                int st = en >= 0 ? en + 1 : -2; /* :186-187 */
-                st = inew > st ? inew : st;
-                st = dnew > st ? dnew : st;
+                const int e_up = wave_from_below(en, -2), e_dn = wave_from_above(en, -2);
+                int st = en + 1;                        /* LV_BAG.cpp:186-187 */
+                st = e_up + top > st ? e_up + top : st; /* I_pos, :166-176,193-194 */
+                st = e_dn + bot > st ? e_dn + bot : st; /* D_pos, :179-182,200-201 */
                 int enew = -2;
                 bool pass = false;
                 if (active && st >= 0) {
@@ -100,7 +90,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void leap_wave_kernel(const uint4* __res
                     pass = enew == len && e + diff <= ASM_LEAP_AF_THRESHOLD; /* :220-238 */
                 }
                 /* lanes outside the band stay at -2 so that they look like the reference's sentinel lanes */
-                en = active ? enew : -2, ip = active ? inew : -2, dp = active ? dnew : -2;
+                en = enew;
                 if (__ballot(pass) != 0ull) {
                     result = e; /* final_ED (LV_BAG.cpp:228,356-358) */
                     break;
