@@ -109,7 +109,7 @@ static hipError_t launch_persistent(asm_handle* h, Kern kern, int64_t n, Args...
 
 template <int K>
 static hipError_t launch_greedy(asm_handle* h, const asm_bucket& b, const GreedyArgs& ga, OutMap out, CigarSink cig) {
-    if (h->persist && ga.x == 1 && ga.o == 1 && ga.e == 1)
+    if (h->persist && ga.x == 1 && ga.o == 1 && ga.e == 1 && !ga.semi)
         return launch_persistent(h, greedy_persist_kernel<K, true>, b.n, (const uint4*)b.planes, (const uint32_t*)b.lens,
                                  (long)b.n, b.w4, ga, out, cig, h->refill_greedy);
     if (h->persist)
@@ -256,6 +256,8 @@ void asm_default_params(asm_params* p) {
     p->p_match = 0.80; /* hurdle_matrix.h:557-559 */
     p->p_mismatch = 0.20 / 3;
     p->p_indel = 0.40 / 3;
+    p->alignment_type = ASM_ALIGN_GLOBAL; /* hurdle_matrix.h:553 default; the harness never passes another */
+    p->reserved_ = 0;
 }
 
 int asm_device_count(void) {
@@ -827,6 +829,8 @@ static int check_params(asm_handle* h, int aligner, const asm_params* p) {
     if (aligner == ASM_GREEDY) {
         if (p->k < 0 || p->k > ASM_GREEDY_MAX_K) return fail(h, ASM_EINVAL, "Greedy: k must be in [0, 50] (MAX_K, hurdle_matrix.h:8)");
         if (!(p->p_match > 0 && p->p_mismatch > 0 && p->p_indel > 0)) return fail(h, ASM_EINVAL, "Greedy: probabilities must be positive");
+        if (p->alignment_type != ASM_ALIGN_GLOBAL && p->alignment_type != ASM_ALIGN_SEMI_GLOBAL)
+            return fail(h, ASM_EUNSUPPORTED, "Greedy: alignment type must be GLOBAL or SEMI_GLOBAL (LOCAL is unsupported in the reference too, hurdle_matrix.h:467)");
     } else if (aligner == ASM_LEAP) {
         if (p->k < 0 || p->k > ASM_WIDE_MAX_K) return fail(h, ASM_EINVAL, "LEAP: k out of range");
         /* the recurrence reads generation e-o / e-ext / e-x: zero penalties would be same-generation reads,
@@ -851,6 +855,7 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
     if (aligner == ASM_GREEDY) {
         GreedyArgs ga;
         ga.x = p->x, ga.o = p->o, ga.e = p->e;
+        ga.semi = p->alignment_type == ASM_ALIGN_SEMI_GLOBAL ? 1 : 0;
         ga.sig_match = log(p->p_match / 0.25); /* hurdle_matrix.h:536-538 */
         ga.sig_mismatch = log(p->p_mismatch / 0.25);
         ga.sig_indel = log(p->p_indel / 2 / 0.25);
@@ -861,7 +866,7 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
             case 4: HIPCHK(h, launch_greedy<4>(h, b, ga, out, cig)); break;
             case 5: HIPCHK(h, launch_greedy<5>(h, b, ga, out, cig)); break;
             default:
-                if (p->k <= ASM_WAVE_MAX_K && h->wave_kernels && unit)
+                if (p->k <= ASM_WAVE_MAX_K && h->wave_kernels && unit && !ga.semi)
                     launch_wave_per_pair(h->stream, greedy_wave_kernel<true>, b.n, h->num_cus, planes, lens, (long)b.n, b.w4,
                                          (int)p->k, ga, out, cig);
                 else if (p->k <= ASM_WAVE_MAX_K && h->wave_kernels && (long)p->o + 62L * p->e < 16000L)

@@ -238,6 +238,8 @@ __global__ __launch_bounds__(ASM_BLOCK) void invert_order_kernel(const uint32_t*
 // --------------------------------------------------------------------------------------------------------
 struct GreedyArgs {
     int x, o, e;
+    int semi; /* SEMI_GLOBAL (hurdle_matrix.h:313-316,335-338,577-580): no switch cost into the first highway, into the
+                 destination lane, or for the final hop */
     double sig_match, sig_mismatch, sig_indel; /* hurdle_matrix.h:536-538, computed on the host with libm */
 };
 
@@ -280,6 +282,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_kernel(const uint4* __restri
     m = m > 128 ? 128 : m; /* hurdle_matrix.h:626-627 */
     nn = nn > 128 ? 128 : nn;
     const int x = args.x, o = args.o, e = args.e;
+    const bool semi = args.semi != 0;
     const int dest_lane = nn - m; /* hurdle_matrix.h:649 */
 
     V128 lo_[NL], lf_[NL];
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_kernel(const uint4* __restri
                     reaching = true;
                 }
             }
-            sw[j] = lane_penalty(cur_lane, lane, o, e);
+            sw[j] = (semi && guard == 0) ? 0 : lane_penalty(cur_lane, lane, o, e);
             nh[j] = v_pop_between(lo_[j], start_col, sp[j] + len[j]);
         }
         double best_h = -__builtin_inf();
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_kernel(const uint4* __restri
             double heur = greedy_significance(args, len[j], nh[j], nsw[j]);
             int leap = -sw[j];
             if (reaching) {
-                const int fsw = lane_penalty(lane, dest_lane, o, e);
+                const int fsw = semi ? 0 : lane_penalty(lane, dest_lane, o, e);
                 heur = (double)(cur_cost - fsw - x * (dst[j] - sp[j] - len[j]));
                 leap -= fsw;
             }
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_kernel(const uint4* __restri
     const int dest_col = lane_destination(m, nn, dest_lane);
     if (cur_lane != dest_lane || cur_col < dest_col) {
         const V128 dv = greedy_lane_vector(A0, A1, B0, B1, dest_lane);
-        const int sw_f = lane_penalty(cur_lane, dest_lane, o, e);
+        const int sw_f = semi ? 0 : lane_penalty(cur_lane, dest_lane, o, e);
         const int distance = v_pop_between(dv, cur_col + fwd_col(cur_lane, dest_lane), dest_col);
         const int hc = x * distance;
         cost += sw_f + (hc > 0 ? hc : 0);
@@ -443,6 +446,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_persist_kernel(const uint4* 
                                                                    CigarSink cig, int refill_min) {
     constexpr int NL = 2 * K + 1;
     const int x = UNIT ? 1 : args.x, o = UNIT ? 1 : args.o, e = UNIT ? 1 : args.e;
+    const bool semi = UNIT ? false : args.semi != 0; /* the UNIT instantiation is GLOBAL only */
     V128 lo_[NL], lf_[NL];
     int sp[NL], len[NL], nsw[NL], dst[NL], sw[NL], nh[NL];
     V128 dest_vec = v_make(0, 0);
@@ -466,7 +470,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_persist_kernel(const uint4* 
                 // ---- final hop (hurdle_matrix.h:575-590) ----
                 const int dest_col = lane_destination(m, nn, dest_lane);
                 if (cur_lane != dest_lane || cur_col < dest_col) {
-                    const int sw_f = lane_penalty(cur_lane, dest_lane, o, e);
+                    const int sw_f = semi ? 0 : lane_penalty(cur_lane, dest_lane, o, e);
                     const int distance = v_pop_between(dest_vec, cur_col + fwd_col(cur_lane, dest_lane), dest_col);
                     const int hc = x * distance;
                     cost += sw_f + (hc > 0 ? hc : 0);
@@ -529,7 +533,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_persist_kernel(const uint4* 
                         reaching = true;
                     }
                 }
-                sw[j] = lane_penalty(cur_lane, lane, o, e);
+                sw[j] = (semi && guard == 0) ? 0 : lane_penalty(cur_lane, lane, o, e);
                 nh[j] = v_pop_between(lo_[j], start_col, sp[j] + len[j]);
             }
             double best_h = -__builtin_inf();
@@ -543,7 +547,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_persist_kernel(const uint4* 
                 double heur = greedy_significance(args, len[j], nh[j], nsw[j]);
                 int leap = -sw[j];
                 if (reaching) {
-                    const int fsw = lane_penalty(lane, dest_lane, o, e);
+                    const int fsw = semi ? 0 : lane_penalty(lane, dest_lane, o, e);
                     heur = (double)(-sw[j] - hc - fsw - x * (dst[j] - sp[j] - len[j]));
                     leap -= fsw;
                 }

@@ -116,6 +116,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_wave_kernel(const uint4* __r
     const bool active = t < nl;
     const int lane = t - k;
     const int x = UNIT ? 1 : args.x, o = UNIT ? 1 : args.o, e = UNIT ? 1 : args.e;
+    const bool semi = UNIT ? false : args.semi != 0;
     for (long i = wave0; i < n; i += nwaves) {
         const V128 A0 = v_from_uint4(planes[((long)0 * w4) * n + i]);
         const V128 A1 = v_from_uint4(planes[((long)1 * w4) * n + i]);
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_wave_kernel(const uint4* __r
                         reach = true;
                     }
                 }
-                sw = lane_penalty(cur_lane, lane, o, e);
+                sw = (semi && guard == 0) ? 0 : lane_penalty(cur_lane, lane, o, e);
                 nh = v_pop_between(lo_, start_col, sp + len);
             }
             const bool reaching = __ballot(reach) != 0ull;
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_wave_kernel(const uint4* __r
             double heur = greedy_significance(args, len, nh, nsw);
             int leap = -sw;
             if (reaching) {
-                const int fsw = lane_penalty(lane, dest_lane, o, e);
+                const int fsw = semi ? 0 : lane_penalty(lane, dest_lane, o, e);
                 heur = (double)(-sw - hc - fsw - x * (dst - sp - len));
                 leap -= fsw;
             }
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_wave_kernel(const uint4* __r
             const int dest_col = lane_destination(m, nn, dest_lane);
             if (cur_lane != dest_lane || cur_col < dest_col) {
                 const V128 dv = greedy_lane_vector(A0, A1, B0, B1, dest_lane);
-                const int sw_f = lane_penalty(cur_lane, dest_lane, o, e);
+                const int sw_f = semi ? 0 : lane_penalty(cur_lane, dest_lane, o, e);
                 const int distance = v_pop_between(dv, cur_col + fwd_col(cur_lane, dest_lane), dest_col);
                 const int hcf = x * distance;
                 cost += sw_f + (hcf > 0 ? hcf : 0);

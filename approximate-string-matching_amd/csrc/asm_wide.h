@@ -148,6 +148,7 @@ __global__ __launch_bounds__(ASM_WIDE_THREADS) void greedy_wide_kernel(const uin
     const bool active = t < nl;
     const int lane = t - k;
     const int x = args.x, o = args.o, e = args.e;
+    const bool semi = args.semi != 0;
     for (long i = blockIdx.x; i < n; i += gridDim.x) {
         const V128 A0 = v_from_uint4(planes[((long)0 * w4) * n + i]);
         const V128 A1 = v_from_uint4(planes[((long)1 * w4) * n + i]);
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(ASM_WIDE_THREADS) void greedy_wide_kernel(const uin
                         reach = 1;
                     }
                 }
-                sw = lane_penalty(cur_lane, lane, o, e);
+                sw = (semi && guard == 0) ? 0 : lane_penalty(cur_lane, lane, o, e);
                 nh = v_pop_between(lo_, start_col, sp + len);
             }
             const int reaching = __syncthreads_or(reach);
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(ASM_WIDE_THREADS) void greedy_wide_kernel(const uin
                 double heur = greedy_significance(args, len, nh, nsw);
                 int leap = -sw;
                 if (reaching) {
-                    const int fsw = lane_penalty(lane, dest_lane, o, e);
+                    const int fsw = semi ? 0 : lane_penalty(lane, dest_lane, o, e);
                     heur = (double)(-sw - hc - fsw - x * (dst - sp - len));
                     leap -= fsw;
                 }
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(ASM_WIDE_THREADS) void greedy_wide_kernel(const uin
             const int dest_col = lane_destination(m, nn, dest_lane);
             if (cur_lane != dest_lane || cur_col < dest_col) {
                 const V128 dv = greedy_lane_vector(A0, A1, B0, B1, dest_lane);
-                const int sw_f = lane_penalty(cur_lane, dest_lane, o, e);
+                const int sw_f = semi ? 0 : lane_penalty(cur_lane, dest_lane, o, e);
                 const int distance = v_pop_between(dv, cur_col + fwd_col(cur_lane, dest_lane), dest_col);
                 const int hc = x * distance;
                 cost += sw_f + (hc > 0 ? hc : 0);

@@ -55,8 +55,9 @@ class hurdle_matrix {
 public:
     explicit hurdle_matrix(alignment_type_t type = GLOBAL, int x = 1, int o = 1, int e = 1, double match_prob = 0.80,
                            double mismatch_prob = 0.20 / 3, double indel_prob = 0.40 / 3) {
-        if (type != GLOBAL) throw std::runtime_error("hurdle_matrix: only GLOBAL is on the accelerated path");
+        if (type == LOCAL) throw std::runtime_error("hurdle_matrix: LOCAL is unsupported (in the reference too, hurdle_matrix.h:467)");
         asm_default_params(&p_);
+        p_.alignment_type = type == SEMI_GLOBAL ? ASM_ALIGN_SEMI_GLOBAL : ASM_ALIGN_GLOBAL;
         p_.x = x, p_.o = o, p_.e = e;
         p_.p_match = match_prob, p_.p_mismatch = mismatch_prob, p_.p_indel = indel_prob;
     }

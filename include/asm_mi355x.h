@@ -60,7 +60,13 @@ typedef struct asm_params {
     double p_match;      /* Greedy significance model; defaults 0.80, 0.20/3, 0.40/3                      */
     double p_mismatch;
     double p_indel;
+    int32_t alignment_type; /* Greedy: ASM_ALIGN_GLOBAL (default, what the harness uses) or ASM_ALIGN_SEMI_GLOBAL —
+                               hurdle_matrix's alignment_type_t (hurdle_matrix.h:477,553; utils.h:554-558); LOCAL is
+                               declared but unsupported in the reference (hurdle_matrix.h:467).  NW and LEAP ignore it. */
+    int32_t reserved_;
 } asm_params;
+#define ASM_ALIGN_GLOBAL 0
+#define ASM_ALIGN_SEMI_GLOBAL 1
 
 /* ---- library / handle ------------------------------------------------------------------------------ */
 const char* asm_version(void);

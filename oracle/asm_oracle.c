@@ -184,7 +184,7 @@ static void cigar_update(cigar_t* c, int best_lane, int curr_lane, int total) {
 }
 
 static int greedy_pair(const uint8_t* Aview, const uint8_t* Bview, int m, int n, int k, int x, int o, int e,
-                       const double sig[3], cigar_t* cg, int* steps_out) {
+                       const double sig[3], cigar_t* cg, int* steps_out, int semi) {
     v128 A0, A1, B0, B1;
     v128 lanes_f[2 * 128 + 1], lanes_o[2 * 128 + 1]; /* index lane+128 (destination lane may be out of band) */
     hw_t hw[2 * 128 + 1];
@@ -219,7 +219,8 @@ static int greedy_pair(const uint8_t* Aview, const uint8_t* Bview, int m, int n,
     }
 
     int cur_lane = 0, cur_col = 0, cost = 0, first = 1, steps = 0;
-    (void)first; /* GLOBAL: the first-step exemption of hurdle_matrix.h:314 never applies */
+    /* SEMI_GLOBAL (semi != 0) zeroes three switch costs: into the first highway (hurdle_matrix.h:313-316), into the
+     * destination lane when a highway reaches it (:335-338), and of the final hop (:577-580) */
 
     for (;;) {
         /* ---- _update_highway_list, hurdle_matrix.h:285-362 ---- */
@@ -240,7 +241,7 @@ static int greedy_pair(const uint8_t* Aview, const uint8_t* Bview, int m, int n,
                     reaching = 1;
                 }
             }
-            h->sw = lane_penalty(cur_lane, lane, o, e);
+            h->sw = (semi && first) ? 0 : lane_penalty(cur_lane, lane, o, e);
             h->nh = v_pop_between(lanes_o[lane + 128], start_col, h->sp + h->len);
             h->hc = x * h->nh;
         }
@@ -259,7 +260,7 @@ static int greedy_pair(const uint8_t* Aview, const uint8_t* Bview, int m, int n,
             double heur = fma(sig[2], (double)h->nsw, fma(sig[1], (double)h->nh, sig[0] * (double)h->len));
             int leap = -h->sw;
             if (reaching) {
-                int fsw = lane_penalty(lane, dest_lane, o, e);
+                int fsw = semi ? 0 : lane_penalty(lane, dest_lane, o, e);
                 heur = cur_cost - fsw - x * (h->dest - h->sp - h->len);
                 leap -= fsw;
             }
@@ -305,7 +306,7 @@ static int greedy_pair(const uint8_t* Aview, const uint8_t* Bview, int m, int n,
     /* ---- final hop, hurdle_matrix.h:575-590 ---- */
     int dest_col = hw[dest_lane + 128].dest;
     if (cur_lane != dest_lane || cur_col < dest_col) {
-        int sw = lane_penalty(cur_lane, dest_lane, o, e);
+        int sw = semi ? 0 : lane_penalty(cur_lane, dest_lane, o, e);
         int distance = v_pop_between(lanes_o[dest_lane + 128], cur_col + fwd_col(cur_lane, dest_lane), dest_col);
         int hc = x * distance;
         cost += sw + (hc > 0 ? hc : 0);
@@ -318,7 +319,15 @@ static int greedy_pair(const uint8_t* Aview, const uint8_t* Bview, int m, int n,
 int orc_greedy_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
                      const uint32_t* ref_off, int k, int x, int o, int e, const double* probs, int mode,
                      int32_t* costs, char* cigars, int cigar_stride, int32_t* steps) {
+    return orc_greedy_batch_typed(n, reads, read_off, refs, ref_off, k, x, o, e, probs, mode, ORC_ALIGN_GLOBAL, costs, cigars,
+                                  cigar_stride, steps);
+}
+
+int orc_greedy_batch_typed(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
+                           const uint32_t* ref_off, int k, int x, int o, int e, const double* probs, int mode,
+                           int alignment_type, int32_t* costs, char* cigars, int cigar_stride, int32_t* steps) {
     if (k < 0 || k > ORC_MAX_K) return -1;
+    if (alignment_type != ORC_ALIGN_GLOBAL && alignment_type != ORC_ALIGN_SEMI_GLOBAL) return -1;
     double sig[3]; /* hurdle_matrix.h:536-538 */
     sig[0] = log(probs[0] / 0.25);
     sig[1] = log(probs[1] / 0.25);
@@ -334,7 +343,8 @@ int orc_greedy_batch(int64_t n, const char* reads, const uint32_t* read_off, con
         cigar_t cg = {cigars ? cigars + i * cigar_stride : NULL, cigar_stride, 0};
         if (cg.buf) cg.buf[0] = 0;
         int st = 0;
-        costs[i] = greedy_pair(views + i * 256, views + i * 256 + 128, m, nn, k, x, o, e, sig, &cg, &st);
+        costs[i] = greedy_pair(views + i * 256, views + i * 256 + 128, m, nn, k, x, o, e, sig, &cg, &st,
+                               alignment_type == ORC_ALIGN_SEMI_GLOBAL);
         if (steps) steps[i] = st;
     }
     free(views);

@@ -37,6 +37,15 @@ int orc_greedy_batch(int64_t n, const char* reads, const uint32_t* read_off, con
                      const uint32_t* ref_off, int k, int x, int o, int e, const double* probs, int mode,
                      int32_t* costs, char* cigars, int cigar_stride, int32_t* steps);
 
+/* Same with the constructor's alignment type (hurdle_matrix.h:477,553): ORC_ALIGN_SEMI_GLOBAL zeroes the switch cost into
+ * the first highway, into the destination lane and of the final hop (hurdle_matrix.h:313-316,335-338,577-580).  LOCAL is
+ * declared but unsupported in the reference (:467). */
+#define ORC_ALIGN_GLOBAL 0
+#define ORC_ALIGN_SEMI_GLOBAL 1
+int orc_greedy_batch_typed(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
+                           const uint32_t* ref_off, int k, int x, int o, int e, const double* probs, int mode,
+                           int alignment_type, int32_t* costs, char* cigars, int cigar_stride, int32_t* steps);
+
 /* The 128-byte A and B buffers each pair's conversion sees (A at views[i*256], B at views[i*256+128]).
  * Model of the in-place permutation of GASMA/bit_convert.cpp:265-330 (SRC table). */
 int orc_greedy_views(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,

@@ -29,8 +29,8 @@ namespace {
 // without touching the reference.
 class greedy_ref : public hurdle_matrix<int_128bit> {
 public:
-    greedy_ref(int x, int o, int e, double pm, double px, double pi)
-        : hurdle_matrix<int_128bit>(GLOBAL, x, o, e, pm, px, pi) {}
+    greedy_ref(alignment_type_t type, int x, int o, int e, double pm, double px, double pi)
+        : hurdle_matrix<int_128bit>(type, x, o, e, pm, px, pi) {}
     void zero_buffers() {
         memset(A, 0, MAX_LENGTH);
         memset(B, 0, MAX_LENGTH);
@@ -50,11 +50,12 @@ extern "C" {
 // cigars (optional): n * cigar_stride bytes, NUL-terminated per pair.
 // views (optional): n * 256 bytes — the 128-byte A and B buffers exactly as _convert_read() will see
 // them (i.e. after strncpy, before conversion) — lets tests validate the stale-tail model directly.
-int ref_greedy_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
-                     const uint32_t* ref_off, int k, int x, int o, int e, double p_match,
-                     double p_mismatch, double p_indel, int mode, int32_t* costs, char* cigars,
-                     int cigar_stride, uint8_t* views) {
-    greedy_ref* g = new greedy_ref(x, o, e, p_match, p_mismatch, p_indel);
+// semi != 0 constructs the aligner with SEMI_GLOBAL instead of GLOBAL (hurdle_matrix.h:553)
+int ref_greedy_batch_typed(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
+                           const uint32_t* ref_off, int k, int x, int o, int e, double p_match,
+                           double p_mismatch, double p_indel, int mode, int semi, int32_t* costs, char* cigars,
+                           int cigar_stride, uint8_t* views) {
+    greedy_ref* g = new greedy_ref(semi ? SEMI_GLOBAL : GLOBAL, x, o, e, p_match, p_mismatch, p_indel);
     g->zero_buffers();
     for (int64_t i = 0; i < n; i++) {
         const char* r = reads + read_off[i];
@@ -83,6 +84,14 @@ int ref_greedy_batch(int64_t n, const char* reads, const uint32_t* read_off, con
     }
     delete g;
     return 0;
+}
+
+int ref_greedy_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
+                     const uint32_t* ref_off, int k, int x, int o, int e, double p_match,
+                     double p_mismatch, double p_indel, int mode, int32_t* costs, char* cigars,
+                     int cigar_stride, uint8_t* views) {
+    return ref_greedy_batch_typed(n, reads, read_off, refs, ref_off, k, x, o, e, p_match, p_mismatch, p_indel, mode, 0, costs,
+                                  cigars, cigar_stride, views);
 }
 
 // full = 1 additionally runs backtrack() and get_CIGAR() as the harness's timed region does (benchmark_utils.h:170-174)

@@ -41,6 +41,7 @@ class Oracle:
         self.lib = lib
         b5 = [_i64, _vp, _vp, _vp, _vp]
         lib.orc_greedy_batch.argtypes = b5 + [_i] * 4 + [_vp, _i, _vp, _vp, _i, _vp]
+        lib.orc_greedy_batch_typed.argtypes = b5 + [_i] * 4 + [_vp, _i, _i, _vp, _vp, _i, _vp]
         lib.orc_greedy_views.argtypes = b5 + [_i, _vp]
         lib.orc_leap_batch.argtypes = b5 + [_i] * 4 + [_vp]
         lib.orc_nw_batch.argtypes = b5 + [_i] * 3 + [_vp]
@@ -54,15 +55,15 @@ class Oracle:
     def set_threads(self, n):
         return self.lib.orc_set_threads(n)
 
-    def greedy(self, hb, k=3, x=1, o=1, e=1, probs=DEFAULT_PROBS, mode=1, cigars=False, steps=False):
+    def greedy(self, hb, k=3, x=1, o=1, e=1, probs=DEFAULT_PROBS, mode=1, cigars=False, steps=False, semi=False):
         keep, args = _batch_args(hb)
         costs = np.zeros(hb.n, np.int32)
         pr = np.array(probs, np.float64)
         cg = np.zeros(hb.n * CIGAR_STRIDE + 1, np.uint8) if cigars else None
         st = np.zeros(hb.n, np.int32) if steps else None
-        rc = self.lib.orc_greedy_batch(*args, k, x, o, e, pr.ctypes.data, mode, costs.ctypes.data,
-                                       cg.ctypes.data if cigars else None, CIGAR_STRIDE,
-                                       st.ctypes.data if steps else None)
+        rc = self.lib.orc_greedy_batch_typed(*args, k, x, o, e, pr.ctypes.data, mode, 1 if semi else 0, costs.ctypes.data,
+                                             cg.ctypes.data if cigars else None, CIGAR_STRIDE,
+                                             st.ctypes.data if steps else None)
         assert rc == 0, rc
         out = [costs]
         if cigars:
@@ -169,18 +170,19 @@ class Reference:
         self.lib = lib
         b5 = [_i64, _vp, _vp, _vp, _vp]
         lib.ref_greedy_batch.argtypes = b5 + [_i] * 4 + [ctypes.c_double] * 3 + [_i, _vp, _vp, _i, _vp]
+        lib.ref_greedy_batch_typed.argtypes = b5 + [_i] * 4 + [ctypes.c_double] * 3 + [_i, _i, _vp, _vp, _i, _vp]
         lib.ref_leap_batch.argtypes = b5 + [_i] * 4 + [_vp, _vp]
         lib.ref_leap_batch_ex.argtypes = b5 + [_i] * 4 + [_vp, _vp, _i]
         lib.ref_convert2bit1.argtypes = [_vp, _vp, _vp]
 
-    def greedy(self, hb, k=3, x=1, o=1, e=1, probs=DEFAULT_PROBS, mode=1, cigars=False, views=False):
+    def greedy(self, hb, k=3, x=1, o=1, e=1, probs=DEFAULT_PROBS, mode=1, cigars=False, views=False, semi=False):
         keep, args = _batch_args(hb)
         costs = np.zeros(hb.n, np.int32)
         cg = np.zeros(hb.n * CIGAR_STRIDE + 1, np.uint8) if cigars else None
         vw = np.zeros(hb.n * 256 + 1, np.uint8) if views else None
-        rc = self.lib.ref_greedy_batch(*args, k, x, o, e, *probs, mode, costs.ctypes.data,
-                                       cg.ctypes.data if cigars else None, CIGAR_STRIDE,
-                                       vw.ctypes.data if views else None)
+        rc = self.lib.ref_greedy_batch_typed(*args, k, x, o, e, *probs, mode, 1 if semi else 0, costs.ctypes.data,
+                                             cg.ctypes.data if cigars else None, CIGAR_STRIDE,
+                                             vw.ctypes.data if views else None)
         assert rc == 0
         out = [costs]
         if cigars:

@@ -508,3 +508,23 @@ def test_filter_state_chains_across_chunks_and_stdin_driver(asm, engine, oracle,
         out = subprocess.run([exe, "--leap-simd", str(ed_t), "--shd", "1" if shd else "0", "--batch-run", "2000"],
                              input=text, capture_output=True, text=True, check=True).stdout.splitlines()
         assert out[0] == "passNum:\t%d" % int(ps.sum()) and out[1] == "totalNum:\t%d" % hb.n, out[:3]
+
+
+@pytest.mark.parametrize("wl,n,k,pen", [("C2", 20000, 3, (1, 1, 1)), ("C5", 8000, 3, (2, 3, 1)), ("C3", 2500, 30, (1, 1, 1)),
+                                        ("C2", 3000, 10, (4, 6, 2)), ("C2", 2000, 40, (1, 1, 1)), ("C1", 4000, 5, (1, 2, 1))])
+def test_greedy_semi_global(asm, engine, oracle, wl, n, k, pen):
+    """asm_params.alignment_type = SEMI_GLOBAL (hurdle_matrix's constructor argument): every Greedy kernel family, cost and
+    CIGAR, both tail modes."""
+    cfg, _, _ = asm.workload(wl)
+    hb = asm.generate_pairs(cfg, 17, n)
+    x, o, e = pen
+    params = asm.Params.default(k=k, x=x, o=o, e=e, alignment_type=asm.ALIGN_SEMI_GLOBAL)
+    for mode in (asm.GREEDY_CLEAN, asm.GREEDY_SEQUENTIAL):
+        batch = engine.upload(hb, mode)
+        want, want_cig = oracle.greedy(hb, k, x, o, e, mode=mode, cigars=True, semi=True)
+        _check(f"semi greedy mode={mode}", engine.align(batch, asm.GREEDY, params), want, hb)
+        cost, cig, _ = engine.greedy_with_cigar(batch, params, cap=96)
+        _check("semi cigar cost", cost, want, hb)
+        assert cig == want_cig
+    with pytest.raises(asm.AsmError):
+        engine.align(batch, asm.GREEDY, asm.Params.default(k=k, alignment_type=2))

@@ -93,3 +93,20 @@ def test_filter_oracle_equals_reference_on_ragged_and_dirty_input(asm, oracle):
         assert np.array_equal(r_ps, o_ps) and np.array_equal(r_ed, o_raw), (t, shd)
     for me in (1, 5, 16):
         assert np.array_equal(ref.shd(hb, me), oracle.shd(hb, me)), me
+
+
+@pytest.mark.parametrize("wl,n,k,pen", [("C2", 30000, 3, (1, 1, 1)), ("C5", 10000, 3, (2, 3, 1)), ("C3", 4000, 30, (1, 1, 1)),
+                                        ("C2", 6000, 10, (4, 6, 2)), ("C4", 10000, 5, (1, 2, 1))])
+def test_semi_global_oracle_equals_reference(asm, oracle, ref, wl, n, k, pen):
+    """hurdle_matrix constructed with SEMI_GLOBAL (hurdle_matrix.h:553): cost and CIGAR, both buffer-tail modes."""
+    cfg, _, _ = asm.workload(wl)
+    hb = asm.generate_pairs(cfg, 4242, n)
+    gd = greedy_defined(hb, k)
+    differs = 0
+    for mode in (0, 1):
+        oc, ocig = oracle.greedy(hb, k, *pen, mode=mode, cigars=True, semi=True)
+        rc, rcig = ref.greedy(hb, k, *pen, mode=mode, cigars=True, semi=True)
+        assert np.array_equal(oc[gd], rc[gd]), (wl, k, pen, mode)
+        assert all(a == b for a, b, d in zip(ocig, rcig, gd) if d), (wl, k, pen, mode, "CIGAR")
+        differs += int((oc != oracle.greedy(hb, k, *pen, mode=mode)).sum())
+    assert differs > 0, "SEMI_GLOBAL must change some costs"
