@@ -71,10 +71,24 @@ ASM_DEV int v_next_one_after_zero_run(V128 l, int fz) {
 
 ASM_DEV int v_popcount(V128 v) { return __popcll(v.lo) + __popcll(v.hi); }
 
-// utils.h:263-270: ones in [from,to); 0 when from+128-to falls outside [0,127] or from outside [0,127].
-ASM_DEV int v_pop_between(V128 v, int from, int to) {
-    return v_popcount(v_away0(v_toward0(v, from), from + 128 - to));
+// ones at index >= s (any s >= 0; 0 from 128 on).  A popcount does not care where the surviving bits end up, so instead of
+// a 128-bit funnel shift this picks the word that s falls into, shifts that one word (the hardware takes the count mod 64)
+// and adds the whole upper word when s is in the lower one.
+ASM_DEV int v_ones_from(V128 v, int s) {
+    const bool low = s < 64;
+    const u64 y = (low ? v.lo : v.hi) >> (s & 63);
+    const int c = __popcll(y) + (low ? __popcll(v.hi) : 0);
+    return s >= 128 ? 0 : c;
 }
+
+// utils.h:263-270 pop_count_between = popcount(shift_right(shift_left(v, from), from + 128 - to)): the ones in [from,to);
+// 0 when `from` or from+128-to falls outside [0,127] (i.e. unless 0 <= from <= 127 and from < to <= from+128).
+// `ones_from_to` = v_ones_from(v, to), which callers that count several ranges with one `to` compute once.
+ASM_DEV int v_pop_between_pre(V128 v, int from, int to, int ones_from_to) {
+    const bool ok = (unsigned)from < 128u && (unsigned)(to - from - 1) < 128u;
+    return ok ? v_ones_from(v, from) - ones_from_to : 0;
+}
+ASM_DEV int v_pop_between(V128 v, int from, int to) { return v_pop_between_pre(v, from, to, v_ones_from(v, to)); }
 
 // utils.h:200-216 with threshold 1: a set bit survives only next to another set bit.
 ASM_DEV V128 v_flip_short_hurdles1(V128 v) {

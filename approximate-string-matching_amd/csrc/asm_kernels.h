@@ -366,6 +366,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_kernel(const uint4* __restri
         if (best_len <= 0) break; /* hurdle_matrix.h:358-361 */
 
         // ---- _choose_best_highway ----
+        const int best_from_sp = v_ones_from(best_vec, best_sp);
         int small_inter = best_cost, small_total = best_cost;
         int ch = best, ch_sp = best_sp, ch_len = best_len, ch_cost = best_cost;
 #pragma unroll
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_kernel(const uint4* __restri
             if (lane != best && !(sp[j] + fwd_col(lane, best) > best_sp)) {
                 const int endp = sp[j] + len[j];
                 const int inter = sw[j] + nh[j]; /* the same range loop 1 counted: [cur_col + fwd, sp + len) */
-                const int tail = x * v_pop_between(best_vec, fwd_col(lane, best) + endp, best_sp);
+                const int tail = x * v_pop_between_pre(best_vec, fwd_col(lane, best) + endp, best_sp, best_from_sp);
                 const int total = inter + lane_penalty(lane, best, o, e) + (tail > 0 ? tail : 0);
                 if (total <= small_total && inter <= small_inter) {
                     small_total = total;
@@ -560,6 +561,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_persist_kernel(const uint4* 
                 finished = true;
             } else {
                 // ---- _choose_best_highway ----
+                const int best_from_sp = v_ones_from(best_vec, best_sp);
                 int small_inter = best_cost, small_total = best_cost;
                 int ch = best, ch_sp = best_sp, ch_len = best_len, ch_cost = best_cost;
 #pragma unroll
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_persist_kernel(const uint4* 
                     if (lane != best && !(sp[j] + fwd_col(lane, best) > best_sp)) {
                         const int endp = sp[j] + len[j];
                         const int inter = sw[j] + nh[j]; /* the same range loop 1 counted: [cur_col + fwd, sp + len) */
-                        const int tail = x * v_pop_between(best_vec, fwd_col(lane, best) + endp, best_sp);
+                        const int tail = x * v_pop_between_pre(best_vec, fwd_col(lane, best) + endp, best_sp, best_from_sp);
                         const int total = inter + lane_penalty(lane, best, o, e) + (tail > 0 ? tail : 0);
                         if (total <= small_total && inter <= small_inter) {
                             small_total = total, small_inter = inter;

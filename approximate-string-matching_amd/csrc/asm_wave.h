@@ -187,11 +187,12 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_wave_kernel(const uint4* __r
             const V128 best_vec = v_make(
                 (u64)(unsigned)lane_read((int)(unsigned)lo_.lo, bt) | ((u64)(unsigned)lane_read((int)(lo_.lo >> 32), bt) << 32),
                 (u64)(unsigned)lane_read((int)(unsigned)lo_.hi, bt) | ((u64)(unsigned)lane_read((int)(lo_.hi >> 32), bt) << 32));
+            const int best_from_sp = v_ones_from(best_vec, best_sp);
             int inter = 0x3fffffff, total = 0x3fffffff;
             if (active && lane != best && !(sp + fwd_col(lane, best) > best_sp)) {
                 const int endp = sp + len;
                 inter = sw + nh;
-                const int tail = x * v_pop_between(best_vec, fwd_col(lane, best) + endp, best_sp);
+                const int tail = x * v_pop_between_pre(best_vec, fwd_col(lane, best) + endp, best_sp, best_from_sp);
                 total = inter + lane_penalty(lane, best, o, e) + (tail > 0 ? tail : 0);
             }
             // The reference folds lanes in ascending order, accepting a lane only if it is no worse than the last

@@ -213,11 +213,12 @@ __global__ __launch_bounds__(ASM_WIDE_THREADS) void greedy_wide_kernel(const uin
             if (t == bt) s_vec[0] = lo_.lo, s_vec[1] = lo_.hi;
             __syncthreads();
             const V128 best_vec = v_make(s_vec[0], s_vec[1]);
+            const int best_from_sp = v_ones_from(best_vec, best_sp);
             int inter = 0x3fffffff, total = 0x3fffffff;
             if (active && lane != best && !(sp + fwd_col(lane, best) > best_sp)) {
                 const int endp = sp + len;
                 inter = sw + v_pop_between(lo_, cur_col + fwd_col(cur_lane, lane), endp);
-                const int tail = x * v_pop_between(best_vec, fwd_col(lane, best) + endp, best_sp);
+                const int tail = x * v_pop_between_pre(best_vec, fwd_col(lane, best) + endp, best_sp, best_from_sp);
                 total = inter + lane_penalty(lane, best, o, e) + (tail > 0 ? tail : 0);
             }
             s_inter[t] = inter, s_total[t] = total;
