@@ -602,19 +602,21 @@ struct VW {
 };
 
 // first set bit at or after `from` in a W64-word vector, or W64*64 when none.  `from` in [0, W64*64].
+// Only the word `from` falls into needs its low bits dropped (one 64-bit shift, taken mod 64 by the hardware); the words
+// above it count from their own bit 0, the words below it not at all.
 template <int W64>
 ASM_DEV int vw_next_one(const VW<W64>& v, int from) {
+    const int q = from >> 6;
+    u64 x = v.w[W64 - 1];
+#pragma unroll
+    for (int qq = W64 - 2; qq >= 0; qq--) x = q == qq ? v.w[qq] : x;
+    const u64 y = x >> (from & 63);
     int res = W64 * 64;
 #pragma unroll
-    for (int q = W64 - 1; q >= 0; q--) {
-        const int base = q * 64;
-        const int rel = from - base; /* bits below `from` are ignored */
-        u64 word = v.w[q];
-        u64 msk = rel <= 0 ? ~0ull : (rel >= 64 ? 0ull : (~0ull << rel));
-        word &= msk;
-        if (word) res = base + __builtin_ctzll(word);
-    }
-    return res;
+    for (int qq = W64 - 1; qq >= 1; qq--) /* descending: the lowest non-empty word above `from` wins */
+        if (qq > q && v.w[qq]) res = qq * 64 + __builtin_ctzll(v.w[qq]);
+    if (y) res = from + __builtin_ctzll(y);
+    return from >= W64 * 64 ? W64 * 64 : res;
 }
 
 // bit p of the result = bit (p - s) of v (bits move away from index 0), s in [0, 63]
