@@ -1315,16 +1315,29 @@ ASM_DEV int nw_band(const uint32_t (&A0)[ND + 2], const uint32_t (&A1)[ND + 2], 
             int rend = nn - W * bq;
             rend = rend > W ? W : rend;
             WT acc = 0;
-            // the block's columns in two runs, [r0, C) and [C, rend): the reservoir's upper word is refilled between
-            // them, which keeps the refill out of the per-column code
+            // the block's columns in two runs: the pattern window of column 32*bq + r starts at row 32*bq + r - (C-1), i.e.
+            // in pattern word bq-1 for r < C-1 and in word bq from there on
 #pragma unroll
             for (int half = 0; half < 2; half++) {
-                const int ra = half == 0 ? r0 : (r0 > C ? r0 : C);
-                const int rb = half == 0 ? (rend < C ? rend : C) : rend;
-                if (half == 1) hi0 = BLK(A0, bq + 1), hi1 = BLK(A1, bq + 1);
+                constexpr int CB = W == 32 ? C - 1 : C;
+                const int ra = half == 0 ? r0 : (r0 > CB ? r0 : CB);
+                const int rb = half == 0 ? (rend < CB ? rend : CB) : rend;
+                if (W != 32 && half == 1) hi0 = BLK(A0, bq + 1), hi1 = BLK(A1, bq + 1);
+                // W = 32: the window is cut straight out of two adjacent pattern words with one v_alignbit_b32 (wave-uniform
+                // shift), no sliding state to update
+                const uint32_t p0l = W == 32 ? (half == 0 ? (bq > 0 ? A0[bq > 0 ? bq - 1 : 0] : 0u) : A0[bq]) : 0u;
+                const uint32_t p0h = W == 32 ? (half == 0 ? A0[bq] : A0[bq + 1]) : 0u;
+                const uint32_t p1l = W == 32 ? (half == 0 ? (bq > 0 ? A1[bq > 0 ? bq - 1 : 0] : 0u) : A1[bq]) : 0u;
+                const uint32_t p1h = W == 32 ? (half == 0 ? A1[bq] : A1[bq + 1]) : 0u;
+                const int shb = half == 0 ? W - CB : -CB;
                 for (int r = ra; r < rb; r++) {
-                    lo0 = (lo0 >> 1) | (hi0 << (W - 1)), hi0 >>= 1;
-                    lo1 = (lo1 >> 1) | (hi1 << (W - 1)), hi1 >>= 1;
+                    if (W == 32) {
+                        lo0 = (WT)__builtin_amdgcn_alignbit(p0h, p0l, (uint32_t)(r + shb));
+                        lo1 = (WT)__builtin_amdgcn_alignbit(p1h, p1l, (uint32_t)(r + shb));
+                    } else {
+                        lo0 = (lo0 >> 1) | (hi0 << (W - 1)), hi0 >>= 1;
+                        lo1 = (lo1 >> 1) | (hi1 << (W - 1)), hi1 >>= 1;
+                    }
                     const WT T0 = band_text_bit<W>(b0, r), T1 = band_text_bit<W>(b1, r);
                     const WT Eq = ~((lo0 ^ T0) | (lo1 ^ T1));
                     const WT D0 = ((((Eq & VPin) + VPin) ^ VPin) | Eq) | VNin;
