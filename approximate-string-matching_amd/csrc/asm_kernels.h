@@ -70,6 +70,7 @@ ASM_DEV void pack_convert(const uint32_t* sb, uint32_t b0, int len, int w4, int 
                         const int a = a0 + (cbase >> 2) + q;
                         d[q] = sb[a ^ (((a >> 5) & 7) << 2)];
                     }
+                    uint32_t g0 = 0u, g1 = 0u; /* flag bytes of the previous (even) dword, gathered */
 #pragma unroll
                     for (int q = 0; q < 8; q++) {
                         const uint32_t ch = __builtin_amdgcn_alignbit(d[q + 1], d[q], sh);
@@ -79,11 +80,17 @@ ASM_DEV void pack_convert(const uint32_t* sb, uint32_t b0, int len, int w4, int 
                         // is code 00 as in bit_convert.cpp:340-355).  plane1 (G|T) = bit 2, plane0 (C|T) = bit 1 ^ bit 2.
                         const uint32_t half = ch >> 1;
                         const uint32_t canon = __builtin_amdgcn_perm(0u, 0x47544341u, half & 0x03030303u);
-                        const uint32_t ok = swar_zero_bytes(canon ^ ch); /* bit 7 of every byte that is a real base */
-                        const uint32_t f0 = ((ch ^ half) << 6) & ok, f1 = (ch << 5) & ok;
-                        /* gather the four byte flags (bits 7,15,23,31) into a nibble */
-                        q0[w] |= ((f0 * 0x00204081u) >> 28) << (4 * q);
-                        q1[w] |= ((f1 * 0x00204081u) >> 28) << (4 * q);
+                        const uint32_t ok = swar_zero_bytes(canon ^ ch) >> 7; /* 0x01 in every byte that is a real base */
+                        const uint32_t f0 = ((ch ^ half) >> 1) & ok, f1 = (ch >> 2) & ok;
+                        /* gather the four byte flags into a nibble with one v_dot4_u32_u8 (weights 1,2,4,8; 16..128 for the odd
+                         * dword, accumulated onto the even one): a byte of the plane word per two dwords */
+                        if ((q & 1) == 0) {
+                            g0 = __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false);
+                            g1 = __builtin_amdgcn_udot4(f1, 0x08040201u, 0u, false);
+                        } else {
+                            q0[w] |= __builtin_amdgcn_udot4(f0, 0x80402010u, g0, false) << (8 * (q >> 1));
+                            q1[w] |= __builtin_amdgcn_udot4(f1, 0x80402010u, g1, false) << (8 * (q >> 1));
+                        }
                     }
                     // characters beyond the string's end (the next pair's bytes in the staging buffer) are dropped here,
                     // once per 32 positions, instead of being masked out of every dword

@@ -59,6 +59,9 @@ BENCH32(k_cndmask, "v_cndmask_b32 %0, %0, %1, vcc")
 BENCH32(k_not, "v_not_b32 %0, %0")
 BENCH32(k_mbcnt, "v_mbcnt_lo_u32_b32 %0, %1, %0")
 BENCH32(k_perm, "v_perm_b32 %0, %0, %1, %1")
+BENCH32(k_dot4, "v_dot4_u32_u8 %0, %0, %1, %0")
+BENCH32(k_bitop3, "v_bitop3_b32 %0, %0, %1, %1 bitop3:0x48")
+BENCH32(k_sad, "v_sad_u8 %0, %0, %1, %0")
 BENCH32(k_dpp_mov, "v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf")
 BENCH32(k_dpp_wave, "v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf")
 BENCH32(k_readlane, "v_readlane_b32 s20, %0, 3\n\tv_xor_b32 %0, s20, %0")
@@ -95,7 +98,7 @@ int main() {
 #define R(k) run(#k, k, 1)
     R(k_xor); R(k_add); R(k_shl); R(k_and_or); R(k_or3); R(k_lshl_or); R(k_add3); R(k_xad); R(k_bfe); R(k_bfi);
     R(k_alignbit); R(k_ffbl); R(k_ffbh); R(k_bcnt); R(k_min); R(k_med3); R(k_mul_lo); R(k_mul24); R(k_mad24);
-    run("k_cmp_cnd", k_cmp_cnd, 2); R(k_cndmask); R(k_not); R(k_mbcnt); R(k_perm); R(k_dpp_mov); R(k_dpp_wave);
+    run("k_cmp_cnd", k_cmp_cnd, 2); R(k_cndmask); R(k_not); R(k_mbcnt); R(k_perm); R(k_dot4); R(k_bitop3); R(k_sad); R(k_dpp_mov); R(k_dpp_wave);
     run("k_readlane", k_readlane, 2);
     R(k_shl64); R(k_shr64); R(k_shr64v); R(k_add64); R(k_fma64); R(k_mul64); R(k_cvt);
     return 0;
