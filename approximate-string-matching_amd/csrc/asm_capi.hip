@@ -35,6 +35,7 @@ struct asm_handle {
     bool bucketing = true;                /* group mixed-length batches by width class (ASM_BUCKET=0 disables) */
     bool wave_kernels = true;             /* wave-per-pair kernels for 6 <= k <= 31 (ASM_WAVE=0: workgroup-per-pair LDS kernels) */
     bool nw_banded = true;                /* banded bit-parallel NW with in-kernel full-height recompute (ASM_NW_BANDED=0) */
+    bool leap_band = true;                /* LEAP, wide band: thread per pair with the band in LDS (ASM_LEAP_BAND=0: wave per pair) */
     bool nw_wfa = true;                   /* affine NW: banded wavefront first, full matrix for the rest (ASM_NW_WFA=0: full matrix only) */
     uint32_t* d_todo = nullptr;           /* affine NW: [0] = count, [1..] = bucket slots the wavefront band could not settle */
     size_t todo_cap = 0;
@@ -293,6 +294,7 @@ int asm_create(asm_handle** out, int device) {
     if ((env = getenv("ASM_WAVE"))) h->wave_kernels = env[0] != '0';
     if ((env = getenv("ASM_NW_BANDED"))) h->nw_banded = env[0] != '0';
     if ((env = getenv("ASM_NW_WFA"))) h->nw_wfa = env[0] != '0';
+    if ((env = getenv("ASM_LEAP_BAND"))) h->leap_band = env[0] != '0';
     if ((env = getenv("ASM_REFILL_GREEDY"))) h->refill_greedy = atoi(env);
     if ((env = getenv("ASM_REFILL_LEAP"))) h->refill_leap = atoi(env);
     *out = h;
@@ -895,6 +897,20 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
                 case 4: HIPCHK(h, launch_leap_general<4>(h, b, p, out)); break;
                 default: HIPCHK(h, launch_leap_general<5>(h, b, p, out)); break;
             }
+        } else if (unit && h->leap_band && h->wave_kernels &&
+                   leap_band_lds((b.maxlen + 31) / 32, (int)p->k, b.maxlen + 2 <= 255 ? 1 : 2) <= 64 * 1024) {
+            /* wide band, unit penalties: thread per pair, band and planes in LDS (asm_wave.h) */
+            const int w32 = (b.maxlen + 31) / 32;
+#define LEAP_BAND(W)                                                                                                        \
+    HIPCHK(h, (b.maxlen + 2 <= 255 ? launch_leap_band<W, uint8_t>(h->stream, planes, lens, b.n, b.w4, (int)p->k, out)       \
+                                   : launch_leap_band<W, uint16_t>(h->stream, planes, lens, b.n, b.w4, (int)p->k, out)))
+            if (w32 <= 4) LEAP_BAND(4);
+            else if (w32 <= 5) LEAP_BAND(5);
+            else if (w32 <= 6) LEAP_BAND(6);
+            else if (w32 <= 8) LEAP_BAND(8);
+            else if (w32 <= 12) LEAP_BAND(12);
+            else LEAP_BAND(16);
+#undef LEAP_BAND
         } else if (unit && p->k <= ASM_WAVE_MAX_K && h->wave_kernels) {
 #define LEAP_WAVE(W) \
     launch_wave_per_pair(h->stream, leap_wave_kernel<W>, b.n, h->num_cus, planes, lens, (long)b.n, b.w4, (int)p->k, out)

@@ -102,6 +102,132 @@ __global__ __launch_bounds__(ASM_BLOCK) void leap_wave_kernel(const uint4* __res
 }
 
 // --------------------------------------------------------------------------------------------------------
+// LEAP, unit penalties, wide band, ONE THREAD PER PAIR with the band in LDS.  In generation e only the lanes |d| <= e can
+// be live, so a wave-per-pair mapping keeps a third of its lanes busy at k = 30 (final_ED ~ 20); here a thread sweeps
+// exactly the live lanes of its own pair.  The lane's `end` values (one int16 per lane, updated in place: the sweep
+// carries the old values of lanes l-1 and l in registers) and the pair's bit planes live in thread-private LDS columns
+// ([row][thread]: conflict-free, no barriers); the lane mask is not materialised — count_ID_length (LV_BAG.cpp:9-23)
+// compares a 32-position window of the read with the window of the reference the lane pairs it with, cut out of the
+// planes with v_alignbit_b32, and stops at the first difference or where either string ends.
+// Same recurrence and results as leap_unit_pair / leap_wave_kernel (LV::run, LV_BAG.cpp:127-245).
+// --------------------------------------------------------------------------------------------------------
+#define LEAP_BAND_THREADS 128
+
+template <int PD> /* plane dwords per string in LDS, one zero dword of padding included */
+ASM_DEV uint32_t leap_band_window(const uint32_t* plane, int pos) {
+    const int q = pos >> 5;
+    return __builtin_amdgcn_alignbit(plane[(q + 1) * LEAP_BAND_THREADS], plane[q * LEAP_BAND_THREADS], (uint32_t)(pos & 31));
+}
+
+// first position p >= from at which lane d sees a mismatch (or either string has run out), as leap_lane_mask defines it
+template <int PD>
+ASM_DEV int leap_band_extend(const uint32_t* pl, int d, int from, int m, int nn) {
+    constexpr int PS = PD * LEAP_BAND_THREADS; /* dwords between planes */
+    const int s = d < 0 ? -d : d;
+    int lim = d < 0 ? m + s : nn + s; /* d < 0: A[p-s] against B[p]; d >= 0: A[p] against B[p-s] */
+    const int other = d < 0 ? nn : m;
+    lim = lim < other ? lim : other;
+    if (from < s || from >= lim) return from;
+    int apos = d < 0 ? from - s : from, bpos = d < 0 ? from : from - s, p = from;
+    for (;;) {
+        const uint32_t diff = (leap_band_window<PD>(pl, apos) ^ leap_band_window<PD>(pl + 2 * PS, bpos)) |
+                              (leap_band_window<PD>(pl + PS, apos) ^ leap_band_window<PD>(pl + 3 * PS, bpos));
+        if (diff) {
+            p += __builtin_ctz(diff);
+            break;
+        }
+        p += 32, apos += 32, bpos += 32;
+        if (p >= lim) break;
+    }
+    return p < lim ? p : lim;
+}
+
+template <int W32, typename EnT> /* plane dwords per string kept in LDS; EnT = int8_t-like storage when every position fits */
+__global__ __launch_bounds__(LEAP_BAND_THREADS) void leap_band_kernel(const uint4* __restrict__ planes,
+                                                                      const uint32_t* __restrict__ lens, long n, int w4,
+                                                                      int k, OutMap out) {
+    constexpr int T = LEAP_BAND_THREADS, PD = W32 + 1;
+    extern __shared__ uint32_t s_band[];
+    uint32_t* const pl = s_band + threadIdx.x;                                   /* [4][PD][T] */
+    EnT* const en = reinterpret_cast<EnT*>(s_band + 4 * PD * T) + threadIdx.x; /* [2k+4][T]: lane l at row l+1, guards 0 and 2k+2;
+                                                                                   stored value = end + 2 (0 = never reached) */
+    const long i = (long)blockIdx.x * T + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t ln = lens[i];
+    const int m = (int)(ln & 0xffffu), nn = (int)(ln >> 16);
+    const int len = m > nn ? m : nn; /* benchmark_utils.h:162 */
+#pragma unroll
+    for (int g = 0; g < (W32 + 3) / 4; g++) {
+#pragma unroll
+        for (int pln = 0; pln < 4; pln++) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (g < w4) v = planes[((long)pln * w4 + g) * n + i];
+            uint32_t* dst = pl + (pln * PD + 4 * g) * T;
+            dst[0] = v.x;
+            if (4 * g + 1 < W32) dst[T] = v.y;
+            if (4 * g + 2 < W32) dst[2 * T] = v.z;
+            if (4 * g + 3 < W32) dst[3 * T] = v.w;
+        }
+    }
+#pragma unroll
+    for (int pln = 0; pln < 4; pln++) pl[(pln * PD + W32) * T] = 0u;
+    const int rows = 2 * k + 4; /* lanes 0..2k at rows 1..2k+1, guard rows 0 and 2k+2, one spare row for the look-ahead read */
+    for (int l = 0; l < rows; l++) en[l * T] = (EnT)0;
+    int result = -1;
+    {   /* e = 0: main diagonal only (LV_BAG.cpp:102-104,131-147) */
+        int e0 = leap_band_extend<PD>(pl, 0, 0, m, nn);
+        e0 = e0 > len ? len : e0;
+        en[(k + 1) * T] = (EnT)(e0 + 2);
+        if (e0 == len) result = 0;
+    }
+    for (int e = 1; e <= ASM_LEAP_AF_THRESHOLD; e++) {
+        if (__ballot(result < 0) == 0ull) break;
+        if (result < 0) {
+            const int lo = k - e > 0 ? k - e : 0, hi = k + e < 2 * k ? k + e : 2 * k;
+            int up_old = (int)en[lo * T] - 2, cur_old = (int)en[(lo + 1) * T] - 2;
+            int dn_old = (int)en[(lo + 2) * T] - 2;
+            bool pass = false;
+            for (int l = lo; l <= hi; l++) {
+                /* the next lane's old value is fetched before this lane's extension, so its LDS latency hides behind it
+                 * (row 2k+3 is a spare guard row the last lane reads and nobody uses) */
+                const int dn_next = (int)en[(l + 3) * T] - 2;
+                const int d = l - k;
+                const int top = d >= 0 ? 1 : 0, bot = d <= 0 ? 1 : 0;
+                int st = cur_old + 1;                         /* LV_BAG.cpp:186-187 */
+                st = up_old + top > st ? up_old + top : st;   /* I_pos (redundant table at o = ext, see leap_unit_pair) */
+                st = dn_old + bot > st ? dn_old + bot : st;   /* D_pos */
+                int enew = -2;
+                if (st >= 0) {
+                    const int from = st > len ? len : st;
+                    int r = leap_band_extend<PD>(pl, d, from, m, nn); /* count_ID_length, :9-23 */
+                    r = r > len ? len : r;
+                    enew = st > len ? st : r;
+                    const int diff = d < 0 ? -d : d;
+                    if (enew == len && e + diff <= ASM_LEAP_AF_THRESHOLD) pass = true; /* :220-238 */
+                }
+                en[(l + 1) * T] = (EnT)(enew + 2);
+                up_old = cur_old, cur_old = dn_old, dn_old = dn_next;
+            }
+            if (pass) result = e; /* final_ED (LV_BAG.cpp:228,356-358) */
+        }
+    }
+    out.put(i, result);
+}
+
+static inline size_t leap_band_lds(int w32, int k, size_t en_bytes) {
+    return (size_t)4 * (w32 + 1) * LEAP_BAND_THREADS * sizeof(uint32_t) + (((size_t)(2 * k + 4) * LEAP_BAND_THREADS * en_bytes + 3) & ~(size_t)3);
+}
+
+template <int W32, typename EnT>
+static inline hipError_t launch_leap_band(hipStream_t stream, const uint4* planes, const uint32_t* lens, int64_t n, int w4, int k,
+                                          OutMap out) {
+    const dim3 grid((unsigned)((n + LEAP_BAND_THREADS - 1) / LEAP_BAND_THREADS)), block(LEAP_BAND_THREADS);
+    hipLaunchKernelGGL((leap_band_kernel<W32, EnT>), grid, block, leap_band_lds(W32, k, sizeof(EnT)), stream, planes, lens,
+                       (long)n, w4, k, out);
+    return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------------------------------
 // Greedy, wave per pair.  Same step structure as greedy_kernel<K> (hurdle_matrix.h:285-434,568-597); lane t of the
 // wave is band lane t - k.
 // --------------------------------------------------------------------------------------------------------
