@@ -874,6 +874,8 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
                 else if (p->k <= ASM_WAVE_MAX_K && h->wave_kernels && (long)p->o + 62L * p->e < 16000L)
                     launch_wave_per_pair(h->stream, greedy_wave_kernel<false>, b.n, h->num_cus, planes, lens, (long)b.n, b.w4,
                                          (int)p->k, ga, out, cig);
+                else if (h->wave_kernels && (long)p->o + 100L * p->e < 16000L)
+                    launch_greedy_wave2(h->stream, planes, lens, b.n, b.w4, (int)p->k, ga, out, cig, h->num_cus);
                 else
                     launch_greedy_wide(h->stream, planes, lens, b.n, b.w4, p->k, ga, out, cig);
                 break;

@@ -357,6 +357,161 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_wave_kernel(const uint4* __r
     }
 }
 
+// --------------------------------------------------------------------------------------------------------
+// Greedy for 32 <= k <= 50 (65..101 band lanes): TWO wavefronts per pair, thread = band lane.  The lane work and the
+// wave-level reductions are those of greedy_wave_kernel; each wave finds its own winner with DPP reductions and the two
+// meet through LDS (three barriers per step).  Replaces the serial per-thread scans of greedy_wide_kernel (which stays
+// as the ASM_WAVE=0 fallback).
+// --------------------------------------------------------------------------------------------------------
+#define GREEDY_WAVE2_THREADS 128
+__global__ __launch_bounds__(GREEDY_WAVE2_THREADS) void greedy_wave2_kernel(const uint4* __restrict__ planes,
+                                                                            const uint32_t* __restrict__ lens, long n, int w4,
+                                                                            int k, GreedyArgs args, OutMap out, CigarSink cig) {
+    __shared__ unsigned long long s_key[2], s_cmask[2];
+    __shared__ int s_kleap[2], s_kbt[2];
+    __shared__ u64 s_vec[2][2];
+    __shared__ int s_sp[GREEDY_WAVE2_THREADS], s_len[GREEDY_WAVE2_THREADS], s_cost[GREEDY_WAVE2_THREADS];
+    __shared__ int s_inter[GREEDY_WAVE2_THREADS], s_total[GREEDY_WAVE2_THREADS];
+    const int t = threadIdx.x, w = t >> 6, tl = t & 63;
+    const int nl = 2 * k + 1;
+    const bool active = t < nl;
+    const int lane = t - k;
+    const int x = args.x, o = args.o, e = args.e;
+    const bool semi = args.semi != 0;
+    for (long i = blockIdx.x; i < n; i += gridDim.x) {
+        const V128 A0 = v_from_uint4(planes[((long)0 * w4) * n + i]);
+        const V128 A1 = v_from_uint4(planes[((long)1 * w4) * n + i]);
+        const V128 B0 = v_from_uint4(planes[((long)2 * w4) * n + i]);
+        const V128 B1 = v_from_uint4(planes[((long)3 * w4) * n + i]);
+        const uint32_t ln = lens[i];
+        int m = (int)(ln & 0xffffu), nn = (int)(ln >> 16);
+        m = m > 128 ? 128 : m; /* hurdle_matrix.h:626-627 */
+        nn = nn > 128 ? 128 : nn;
+        const int dest_lane = nn - m;
+        const V128 lo_ = greedy_lane_vector(A0, A1, B0, B1, lane);
+        const V128 lf_ = v_flip_short_hurdles1(lo_);
+        int sp = -1, len = 0, nsw = 128;
+        const int dst = lane_destination(m, nn, lane);
+        int cur_lane = 0, cur_col = 0, cost = 0, ncig = 0;
+        const long pair = out.index(i);
+        for (int guard = 0; guard < 4 * 128; guard++) {
+            // ---- _update_highway_list, one band lane per thread ----
+            int reach = 0, sw = 0, nh = 0;
+            if (active) {
+                const int start_col = cur_col + fwd_col(cur_lane, lane);
+                if (sp < start_col) {
+                    const int dd = lane - cur_lane;
+                    nsw = dd < 0 ? -dd : dd;
+                    const V128 l = v_toward0(lf_, start_col);
+                    const int fz = v_first_zero(l);
+                    const int nx = v_next_one_after_zero_run(l, fz);
+                    sp = start_col + fz;
+                    len = nx;
+                    if (start_col + fz + nx > dst) {
+                        const int c = dst - (start_col + fz);
+                        len = c > 0 ? c : 0;
+                        reach = 1;
+                    }
+                }
+                sw = (semi && guard == 0) ? 0 : lane_penalty(cur_lane, lane, o, e);
+                nh = v_pop_between(lo_, start_col, sp + len);
+            }
+            const int reaching = __syncthreads_or(reach);
+            const int hc = x * nh;
+            double heur = greedy_significance(args, len, nh, nsw);
+            int leap = -sw;
+            if (reaching) {
+                const int fsw = semi ? 0 : lane_penalty(lane, dest_lane, o, e);
+                heur = (double)(-sw - hc - fsw - x * (dst - sp - len));
+                leap -= fsw;
+            }
+            // arg-max of (heur, leap) inside the wave, first lane wins exact ties (hurdle_matrix.h:345-351)
+            heur = heur + 0.0; /* -0.0 -> +0.0 so that equal values have equal keys */
+            const unsigned long long hb = (unsigned long long)__double_as_longlong(heur);
+            const unsigned long long key = (hb >> 63) ? ~hb : (hb | 0x8000000000000000ull);
+            const unsigned khi = active ? (unsigned)(key >> 32) : 0u;
+            const unsigned mhi = wave_max_u32(khi);
+            bool cand = active && khi == mhi;
+            const unsigned klo = cand ? (unsigned)key : 0u;
+            const unsigned mlo = wave_max_u32(klo);
+            cand = cand && klo == mlo;
+            const unsigned k3 = cand ? ((((unsigned)(leap + 32768)) << 6) | (unsigned)(63 - tl)) : 0u;
+            const unsigned m3 = wave_max_u32(k3);
+            const int btl = 63 - (int)(m3 & 63u);
+            if (tl == btl) { /* this wave's winner (wave 1 always has active lanes: nl >= 65) */
+                s_key[w] = active ? key : 0ull;
+                s_kleap[w] = leap;
+                s_kbt[w] = t;
+                s_vec[w][0] = lo_.lo, s_vec[w][1] = lo_.hi;
+            }
+            s_sp[t] = sp, s_len[t] = len, s_cost[t] = sw + hc;
+            __syncthreads();
+            const bool take1 = s_key[1] > s_key[0] || (s_key[1] == s_key[0] && s_kleap[1] > s_kleap[0]); /* ties: lower lane */
+            const int bt = take1 ? s_kbt[1] : s_kbt[0];
+            const int best = bt - k, best_sp = s_sp[bt], best_len = s_len[bt], best_cost = s_cost[bt];
+            if (best_len <= 0) break; /* hurdle_matrix.h:358-361 — uniform across the workgroup */
+            // ---- _choose_best_highway ----
+            const V128 best_vec = v_make(s_vec[take1 ? 1 : 0][0], s_vec[take1 ? 1 : 0][1]);
+            const int best_from_sp = v_ones_from(best_vec, best_sp);
+            int inter = 0x3fffffff, total = 0x3fffffff;
+            if (active && lane != best && !(sp + fwd_col(lane, best) > best_sp)) {
+                const int endp = sp + len;
+                inter = sw + nh;
+                const int tail = x * v_pop_between_pre(best_vec, fwd_col(lane, best) + endp, best_sp, best_from_sp);
+                total = inter + lane_penalty(lane, best, o, e) + (tail > 0 ? tail : 0);
+            }
+            // lanes that can still be accepted (thresholds only go down from best_cost), folded in lane order
+            const unsigned long long cm = __ballot(total <= best_cost && inter <= best_cost);
+            if (tl == 0) s_cmask[w] = cm;
+            s_inter[t] = inter, s_total[t] = total;
+            __syncthreads();
+            int small_total = best_cost, small_inter = best_cost, ct = bt;
+#pragma unroll
+            for (int ww = 0; ww < 2; ww++) {
+                unsigned long long cmask = s_cmask[ww];
+                while (cmask) {
+                    const int j = 64 * ww + __builtin_ctzll(cmask);
+                    cmask &= cmask - 1ull;
+                    const int tj = s_total[j], ij = s_inter[j];
+                    if (tj <= small_total && ij <= small_inter) small_total = tj, small_inter = ij, ct = j;
+                }
+            }
+            // ---- _step commit (hurdle_matrix.h:411-433) ----
+            cost += s_cost[ct];
+            const int new_col = s_sp[ct] + s_len[ct];
+            if (cig.on() && t == 0) cig.step(pair, ncig, cur_lane, ct - k, new_col - (cur_col + fwd_col(cur_lane, ct - k)));
+            cur_lane = ct - k;
+            cur_col = new_col;
+            const bool done = cur_col >= lane_destination(m, nn, cur_lane);
+            __syncthreads(); /* the LDS arrays are rewritten by the next step */
+            if (done) break;
+        }
+        if (t == 0) {
+            // ---- final hop (hurdle_matrix.h:575-590) ----
+            const int dest_col = lane_destination(m, nn, dest_lane);
+            if (cur_lane != dest_lane || cur_col < dest_col) {
+                const V128 dv = greedy_lane_vector(A0, A1, B0, B1, dest_lane);
+                const int sw_f = semi ? 0 : lane_penalty(cur_lane, dest_lane, o, e);
+                const int distance = v_pop_between(dv, cur_col + fwd_col(cur_lane, dest_lane), dest_col);
+                const int hcf = x * distance;
+                cost += sw_f + (hcf > 0 ? hcf : 0);
+                if (cig.on()) cig.step(pair, ncig, cur_lane, dest_lane, distance);
+            }
+            if (cig.on()) cig.finish(pair, ncig);
+            out.put(i, cost);
+        }
+        __syncthreads();
+    }
+}
+
+static inline void launch_greedy_wave2(hipStream_t stream, const uint4* planes, const uint32_t* lens, int64_t n, int w4, int k,
+                                       const GreedyArgs& ga, OutMap out, CigarSink cig, int num_cus) {
+    int64_t blocks = (int64_t)num_cus * 16; /* two waves each; the kernel strides over the pairs */
+    if (blocks > n) blocks = n;
+    hipLaunchKernelGGL(greedy_wave2_kernel, dim3((unsigned)blocks), dim3(GREEDY_WAVE2_THREADS), 0, stream, planes, lens, (long)n,
+                       w4, k, ga, out, cig);
+}
+
 template <typename Kern, typename... Args>
 static inline void launch_wave_per_pair(hipStream_t stream, Kern kern, int64_t n, int num_cus, Args... args) {
     int per_cu = 8;
