@@ -913,6 +913,25 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
             else if (w32 <= 12) LEAP_BAND(12);
             else LEAP_BAND(16);
 #undef LEAP_BAND
+        } else if (!unit && h->leap_band && h->wave_kernels &&
+                   leap_band_general_lds((b.maxlen + 31) / 32, (int)p->k, RingGeometry(p->x, p->o, p->e).gm,
+                                         RingGeometry(p->x, p->o, p->e).gi, b.maxlen + 2 <= 255 ? 1 : 2) <= 64 * 1024) {
+            /* wide band, general penalties: thread per pair, generation rings and planes in LDS (asm_wave.h) */
+            const RingGeometry rg(p->x, p->o, p->e);
+            const int w32 = (b.maxlen + 31) / 32;
+#define LEAP_BANDG(W)                                                                                                          \
+    HIPCHK(h, (b.maxlen + 2 <= 255                                                                                              \
+                   ? launch_leap_band_general<W, uint8_t>(h->stream, planes, lens, b.n, b.w4, (int)p->k, (int)p->x, (int)p->o,   \
+                                                          (int)p->e, rg.gm, rg.gi, out)                                          \
+                   : launch_leap_band_general<W, uint16_t>(h->stream, planes, lens, b.n, b.w4, (int)p->k, (int)p->x, (int)p->o,  \
+                                                           (int)p->e, rg.gm, rg.gi, out)))
+            if (w32 <= 4) LEAP_BANDG(4);
+            else if (w32 <= 5) LEAP_BANDG(5);
+            else if (w32 <= 6) LEAP_BANDG(6);
+            else if (w32 <= 8) LEAP_BANDG(8);
+            else if (w32 <= 12) LEAP_BANDG(12);
+            else LEAP_BANDG(16);
+#undef LEAP_BANDG
         } else if (unit && p->k <= ASM_WAVE_MAX_K && h->wave_kernels) {
 #define LEAP_WAVE(W) \
     launch_wave_per_pair(h->stream, leap_wave_kernel<W>, b.n, h->num_cus, planes, lens, (long)b.n, b.w4, (int)p->k, out)

@@ -228,6 +228,131 @@ static inline hipError_t launch_leap_band(hipStream_t stream, const uint4* plane
 }
 
 // --------------------------------------------------------------------------------------------------------
+// LEAP, general penalties (x, o, ext), wide band: the thread-per-pair form of leap_band_kernel with the generation
+// rings of leap_general_kernel — `end` over gm = 2^a > max(x, o) generations, I and D over gi = 2^b > ext — as bytes or
+// shorts in thread-private LDS columns [ring slot][lane row][thread].  Lane d can only be live once a gap of |d| is
+// affordable, e >= o + (|d|-1) ext, so generation e sweeps |d| <= dmax(e); dmax never shrinks, hence whatever a slot
+// still holds beyond it from gm generations earlier is the "never reached" code and nothing needs clearing after the
+// initial zero fill (0 = -2: values are stored +2).
+// --------------------------------------------------------------------------------------------------------
+#define LEAP_BANDG_THREADS 64
+template <int W32, typename EnT>
+__global__ __launch_bounds__(LEAP_BANDG_THREADS) void leap_band_general_kernel(const uint4* __restrict__ planes,
+                                                                               const uint32_t* __restrict__ lens, long n, int w4,
+                                                                               int k, int x, int o, int ext, int gm, int gi,
+                                                                               OutMap out) {
+    constexpr int T = LEAP_BANDG_THREADS, PD = W32 + 1;
+    static_assert(LEAP_BANDG_THREADS == 64 && LEAP_BAND_THREADS == 128, "leap_band_window strides by LEAP_BAND_THREADS");
+    extern __shared__ uint32_t s_band[];
+    const int rows = 2 * k + 3; /* lane l at row l+1, guard rows 0 and 2k+2 */
+    const int slot = rows * T;  /* elements per ring slot */
+    // planes use the stride of leap_band_window (LEAP_BAND_THREADS): two blocks' worth of columns, this block uses the first 64
+    uint32_t* const pl = s_band + threadIdx.x;                                        /* [4][PD][LEAP_BAND_THREADS] */
+    EnT* const r_en = reinterpret_cast<EnT*>(s_band + 4 * PD * LEAP_BAND_THREADS) + threadIdx.x; /* [gm][rows][T] */
+    EnT* const r_ip = r_en + gm * slot;                                               /* [gi][rows][T] */
+    EnT* const r_dp = r_ip + gi * slot;
+    {   /* zero fill of all rings by the whole block */
+        const int words = (int)(((size_t)(gm + 2 * gi) * slot * sizeof(EnT) + 3) / 4);
+        uint32_t* const base = s_band + 4 * PD * LEAP_BAND_THREADS;
+        for (int q = threadIdx.x; q < words; q += T) base[q] = 0u;
+    }
+    __syncthreads();
+    const long i = (long)blockIdx.x * T + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t ln = lens[i];
+    const int m = (int)(ln & 0xffffu), nn = (int)(ln >> 16);
+    const int len = m > nn ? m : nn; /* benchmark_utils.h:162 */
+#pragma unroll
+    for (int g = 0; g < (W32 + 3) / 4; g++) {
+#pragma unroll
+        for (int pln = 0; pln < 4; pln++) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (g < w4) v = planes[((long)pln * w4 + g) * n + i];
+            uint32_t* dst = pl + (pln * PD + 4 * g) * LEAP_BAND_THREADS;
+            dst[0] = v.x;
+            if (4 * g + 1 < W32) dst[LEAP_BAND_THREADS] = v.y;
+            if (4 * g + 2 < W32) dst[2 * LEAP_BAND_THREADS] = v.z;
+            if (4 * g + 3 < W32) dst[3 * LEAP_BAND_THREADS] = v.w;
+        }
+    }
+#pragma unroll
+    for (int pln = 0; pln < 4; pln++) pl[(pln * PD + W32) * LEAP_BAND_THREADS] = 0u;
+    int result = -1;
+    {   /* e = 0: main diagonal only (LV_BAG.cpp:102-104,131-147) */
+        int e0 = leap_band_extend<PD>(pl, 0, 0, m, nn);
+        e0 = e0 > len ? len : e0;
+        r_en[(k + 1) * T] = (EnT)(e0 + 2);
+        if (e0 == len) result = 0;
+    }
+    for (int e = 1; e <= ASM_LEAP_AF_THRESHOLD; e++) {
+        if (__ballot(result < 0) == 0ull) break;
+        if (result < 0) {
+            int dmax = e < o ? 0 : (e - o) / ext + 1;
+            dmax = dmax > k ? k : dmax;
+            const EnT* const en_o = r_en + ((e - o) & (gm - 1)) * slot;
+            const EnT* const en_x = r_en + ((e - x) & (gm - 1)) * slot;
+            const EnT* const ip_e = r_ip + ((e - ext) & (gi - 1)) * slot;
+            const EnT* const dp_e = r_dp + ((e - ext) & (gi - 1)) * slot;
+            EnT* const en_w = r_en + (e & (gm - 1)) * slot;
+            EnT* const ip_w = r_ip + (e & (gi - 1)) * slot;
+            EnT* const dp_w = r_dp + (e & (gi - 1)) * slot;
+            const bool has_o = e >= o, has_e = e >= ext, has_x = e >= x;
+            bool pass = false;
+            for (int l = k - dmax; l <= k + dmax; l++) {
+                const int d = l - k;
+                const int top = d >= 0 ? 1 : 0, bot = d <= 0 ? 1 : 0;
+                const int e_up = has_o ? (int)en_o[l * T] - 2 : -2;       /* lane l-1 sits at row l */
+                const int i_up = has_e ? (int)ip_e[l * T] - 2 : -2;
+                const int e_dn = has_o ? (int)en_o[(l + 2) * T] - 2 : -2; /* lane l+1 */
+                const int d_dn = has_e ? (int)dp_e[(l + 2) * T] - 2 : -2;
+                const int own = has_x ? (int)en_x[(l + 1) * T] - 2 : -2;
+                int inew = -2, dnew = -2;
+                if (e_up >= 0 && e_up > i_up)
+                    inew = e_up + top; /* LV_BAG.cpp:166-167 */
+                else if (i_up >= 0)
+                    inew = i_up + top; /* :172-176 */
+                if (e_dn >= 0 && e_dn > d_dn)
+                    dnew = e_dn + bot; /* :179-180 */
+                else if (d_dn >= 0)
+                    dnew = d_dn + bot; /* :181-182 */
+                int st = own >= 0 ? own + 1 : -2; /* :186-187 */
+                st = inew > st ? inew : st;
+                st = dnew > st ? dnew : st;
+                int enew = -2;
+                if (st >= 0) {
+                    const int from = st > len ? len : st;
+                    int r = leap_band_extend<PD>(pl, d, from, m, nn); /* count_ID_length, :9-23 */
+                    r = r > len ? len : r;
+                    enew = st > len ? st : r;
+                    if (enew == len) { /* :220-238 */
+                        const int diff = d < 0 ? -d : d;
+                        const int conv = e + (diff ? o + (diff - 1) * ext : 0);
+                        if (conv <= ASM_LEAP_AF_THRESHOLD) pass = true;
+                    }
+                }
+                en_w[(l + 1) * T] = (EnT)(enew + 2), ip_w[(l + 1) * T] = (EnT)(inew + 2), dp_w[(l + 1) * T] = (EnT)(dnew + 2);
+            }
+            if (pass) result = e; /* final_ED (LV_BAG.cpp:228,356-358) */
+        }
+    }
+    out.put(i, result);
+}
+
+static inline size_t leap_band_general_lds(int w32, int k, int gm, int gi, size_t en_bytes) {
+    return (size_t)4 * (w32 + 1) * LEAP_BAND_THREADS * sizeof(uint32_t) +
+           (((size_t)(gm + 2 * gi) * (2 * k + 3) * LEAP_BANDG_THREADS * en_bytes + 3) & ~(size_t)3);
+}
+
+template <int W32, typename EnT>
+static inline hipError_t launch_leap_band_general(hipStream_t stream, const uint4* planes, const uint32_t* lens, int64_t n, int w4,
+                                                  int k, int x, int o, int e, int gm, int gi, OutMap out) {
+    const dim3 grid((unsigned)((n + LEAP_BANDG_THREADS - 1) / LEAP_BANDG_THREADS)), block(LEAP_BANDG_THREADS);
+    hipLaunchKernelGGL((leap_band_general_kernel<W32, EnT>), grid, block, leap_band_general_lds(W32, k, gm, gi, sizeof(EnT)), stream,
+                       planes, lens, (long)n, w4, k, x, o, e, gm, gi, out);
+    return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------------------------------
 // Greedy, wave per pair.  Same step structure as greedy_kernel<K> (hurdle_matrix.h:285-434,568-597); lane t of the
 // wave is band lane t - k.
 // --------------------------------------------------------------------------------------------------------
