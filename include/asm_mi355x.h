@@ -5,7 +5,9 @@
  *   NW     `_run_nw_sse`  benchmark_utils.h:130-150  (parasail_nw_trace_striped_sse41_128_16; penalty = -score)
  *   LEAP   `_run_LEAP`    benchmark_utils.h:156-179  (LV::load_reads/reset/run/get_ED, LEAP_SIMD/LV_BAG.cpp:110-245,356)
  *   Greedy `_run_greedy`  benchmark_utils.h:185-201  (hurdle_matrix<int_128bit>::reset/run/get_cost, hurdle_matrix.h:568,625,677)
- * plus the accuracy counters of benchmark_utils.h:249-255 and the input definition of benchmark_dataset.h.
+ * plus the accuracy counters of benchmark_utils.h:249-255, the coverage metric (:214-225,256), the input definition of
+ * benchmark_dataset.h, the mapper's per-hit call shape (GASMA/mapper/main.cpp:77-96) and the filtering stage in front of the
+ * aligners (bit-parallel LEAP `SIMD_ED` and SHD, GASMA/benchmark/LEAP_SIMD/main.cpp:95-101,186-195).
  * The reference runs these one pair at a time on one CPU thread; this library runs a whole batch of pairs
  * per call on one GPU.  Plain pointers and sizes only; no C++/torch types cross this boundary.
  *
