@@ -133,6 +133,8 @@ def load_library() -> ctypes.CDLL:
         "asm_coverage": (i32, [vp, vp, c.POINTER(Params), vp, i32, vp, i32, vp, vp, i32, vp, vp]),
         "asm_simd_ed_batch_async": (i32, [vp, vp, i32, i32, i32, vp, vp]),
         "asm_shd_filter_batch_async": (i32, [vp, vp, i32, vp]),
+        "asm_profile_enable": (i32, [vp, i32, c.c_uint32]),
+        "asm_profile_read": (i32, [vp, vp, i32, vp]),
         "asm_count_equal_async": (i32, [vp, vp, vp, i64, vp]),
         "asm_accuracy_async": (i32, [vp, vp, vp, vp, vp, i64, vp]),
         "asm_run_benchmark_async": (i32, [vp, vp, c.POINTER(Params), i32, vp, vp, vp, vp, vp]),
@@ -495,6 +497,18 @@ class Engine:
                                                    d_leap, d_greedy, d_answers, d_counters))
 
     # ---- timing ----
+    def profile_enable(self, max_calls: int, kernel_mask: int = 0xF) -> None:
+        """The next max_calls run_benchmark_async calls time the selected kernels (bit 0 pack, 1 NW, 2 LEAP, 3 Greedy) with
+        events on the launching streams."""
+        self._chk(self.lib.asm_profile_enable(self.h, int(max_calls), int(kernel_mask)))
+
+    def profile_read(self, cap_calls: int) -> np.ndarray:
+        """-> float32[calls][4] = ms of (pack, nw, leap, greedy) per recorded call, -1 where not launched; synchronises."""
+        ms = np.full((max(cap_calls, 1), 4), -1.0, np.float32)
+        n = ctypes.c_int(0)
+        self._chk(self.lib.asm_profile_read(self.h, ms.ctypes.data, int(cap_calls), ctypes.byref(n)))
+        return ms[:min(n.value, cap_calls)]
+
     def timer(self) -> "Timer":
         return Timer(self)
 

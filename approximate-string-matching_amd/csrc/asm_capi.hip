@@ -37,6 +37,10 @@ struct asm_handle {
     bool nw_banded = true;                /* banded bit-parallel NW with in-kernel full-height recompute (ASM_NW_BANDED=0) */
     bool leap_band = true;                /* LEAP, wide band: thread per pair with the band in LDS (ASM_LEAP_BAND=0: wave per pair) */
     bool nw_wfa = true;                   /* affine NW: banded wavefront first, full matrix for the rest (ASM_NW_WFA=0: full matrix only) */
+    std::vector<hipEvent_t> prof_ev;      /* asm_profile_enable: 8 events per recorded asm_run_benchmark_async call */
+    std::vector<unsigned> prof_mask;      /* which of a call's four kernels were launched */
+    int prof_cap = 0;
+    unsigned prof_select = 0xfu;          /* which kernels are bracketed: bit 0 pack, 1 NW, 2 LEAP, 3 Greedy */
     uint32_t* d_todo = nullptr;           /* affine NW: [0] = count, [1..] = bucket slots the wavefront band could not settle */
     size_t todo_cap = 0;
 };
@@ -309,6 +313,7 @@ int asm_destroy(asm_handle* h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->d_todo) (void)hipFree(h->d_todo);
+    for (hipEvent_t ev : h->prof_ev) (void)hipEventDestroy(ev);
     delete h;
     return ASM_OK;
 }
@@ -1208,32 +1213,93 @@ int asm_accuracy_async(asm_handle* h, const int32_t* d_nw, const int32_t* d_leap
     return ASM_OK;
 }
 
+int asm_profile_enable(asm_handle* h, int max_calls, unsigned kernel_mask) {
+    if (!h || max_calls < 0) return fail(h, ASM_EINVAL, "asm_profile_enable: bad argument");
+    h->prof_select = kernel_mask & 0xfu;
+    HIPCHK(h, hipSetDevice(h->device));
+    for (hipEvent_t ev : h->prof_ev) (void)hipEventDestroy(ev);
+    h->prof_ev.clear();
+    h->prof_mask.clear();
+    h->prof_cap = 0;
+    for (int i = 0; i < 8 * max_calls; i++) {
+        hipEvent_t ev;
+        HIPCHK(h, hipEventCreate(&ev));
+        h->prof_ev.push_back(ev);
+    }
+    h->prof_cap = max_calls;
+    return ASM_OK;
+}
+
+int asm_profile_read(asm_handle* h, float* ms, int cap_calls, int* n_calls) {
+    if (!h || !n_calls || (cap_calls > 0 && !ms)) return fail(h, ASM_EINVAL, "asm_profile_read: NULL argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->side_stream) HIPCHK(h, hipStreamSynchronize(h->side_stream));
+    const int n = (int)h->prof_mask.size();
+    *n_calls = n;
+    for (int c = 0; c < n && c < cap_calls; c++)
+        for (int q = 0; q < 4; q++) {
+            float v = -1.0f;
+            if (h->prof_mask[(size_t)c] & (1u << q))
+                HIPCHK(h, hipEventElapsedTime(&v, h->prof_ev[(size_t)(8 * c + 2 * q)], h->prof_ev[(size_t)(8 * c + 2 * q + 1)]));
+            ms[4 * c + q] = v;
+        }
+    return ASM_OK;
+}
+
 int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, int repack, int32_t* d_nw,
                             int32_t* d_leap, int32_t* d_greedy, const int32_t* d_answers,
                             unsigned long long* d_counters) {
     if (!h || !b || !p) return fail(h, ASM_EINVAL, "asm_run_benchmark_async: NULL argument");
     int rc = ASM_OK;
-    if (repack) rc = asm_batch_pack_async(h, b);
+    // optional per-kernel timing inside the caller's timed region: events on the stream each kernel is launched on
+    hipEvent_t* pe = nullptr;
+    unsigned pmask = 0u;
+    if ((int)h->prof_mask.size() < h->prof_cap) pe = &h->prof_ev[8 * h->prof_mask.size()];
+#define PROF(q, which, stream_)                                              \
+    if (pe && !rc && (h->prof_select & (1u << (q)))) {                       \
+        HIPCHK(h, hipEventRecord(pe[2 * (q) + (which)], (stream_)));         \
+        pmask |= 1u << (q);                                                  \
+    }
+    hipStream_t main_stream = h->stream;
+    if (repack) {
+        PROF(0, 0, main_stream)
+        rc = asm_batch_pack_async(h, b);
+        PROF(0, 1, main_stream)
+    }
     // Greedy depends only on the packed planes, NW -> LEAP form their own chain (LEAP is scheduled by the NW penalties):
     // run Greedy on a side stream so that the two chains fill each other's launch gaps and tail waves.
     const bool fork = h->overlap && d_greedy && (d_nw || d_leap) && !rc;
-    hipStream_t main_stream = h->stream;
     if (fork) {
         HIPCHK(h, hipEventRecord(h->ev_fork, main_stream));
         HIPCHK(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+        PROF(3, 0, h->side_stream)
         h->stream = h->side_stream;
         rc = asm_align_batch_async(h, b, ASM_GREEDY, p, d_greedy);
         h->stream = main_stream;
+        PROF(3, 1, h->side_stream)
         if (!rc) HIPCHK(h, hipEventRecord(h->ev_join, h->side_stream));
     }
-    if (!rc && d_nw) rc = asm_align_batch_async(h, b, ASM_NW, p, d_nw);
+    if (!rc && d_nw) {
+        PROF(1, 0, main_stream)
+        rc = asm_align_batch_async(h, b, ASM_NW, p, d_nw);
+        PROF(1, 1, main_stream)
+    }
     /* LEAP is scheduled by the NW penalties just computed (same work, sorted inside each workgroup) */
-    if (!rc && d_leap) rc = asm_align_batch_hinted_async(h, b, ASM_LEAP, p, d_nw, d_leap);
+    if (!rc && d_leap) {
+        PROF(2, 0, main_stream)
+        rc = asm_align_batch_hinted_async(h, b, ASM_LEAP, p, d_nw, d_leap);
+        PROF(2, 1, main_stream)
+    }
     if (fork) {
         if (!rc) HIPCHK(h, hipStreamWaitEvent(main_stream, h->ev_join, 0));
     } else if (!rc && d_greedy) {
+        PROF(3, 0, main_stream)
         rc = asm_align_batch_async(h, b, ASM_GREEDY, p, d_greedy);
+        PROF(3, 1, main_stream)
     }
+#undef PROF
+    if (pe) h->prof_mask.push_back(pmask);
     if (!rc && d_counters && d_nw) rc = asm_accuracy_async(h, d_nw, d_leap, d_greedy, d_answers, b->n, d_counters);
     return rc;
 }

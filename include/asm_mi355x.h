@@ -199,6 +199,15 @@ int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, in
                             int32_t* d_leap, int32_t* d_greedy, const int32_t* d_answers,
                             unsigned long long* d_counters);
 
+/* Per-kernel timing INSIDE a caller's timed region: after asm_profile_enable(h, max_calls, kernel_mask) the next max_calls
+ * calls of asm_run_benchmark_async bracket the selected kernels (bit 0 pack, 1 NW, 2 LEAP, 3 Greedy) with HIP events
+ * recorded on the stream that kernel is launched on (Greedy: the handle's side stream); asm_profile_read synchronises and
+ * returns ms[call][4] (-1 where a kernel was not launched or not selected).  An event record keeps the next kernel of its
+ * stream from starting early, so bracket only what is needed: all four cost ~8 % of the C2 step, Greedy alone (its own
+ * stream) ~1 %.  asm_profile_enable(h, 0, 0) switches it off. */
+int asm_profile_enable(asm_handle* h, int max_calls, unsigned kernel_mask);
+int asm_profile_read(asm_handle* h, float* ms, int cap_calls, int* n_calls);
+
 /* ---- plain device memory helpers (so that non-torch hosts can drive the async API) --------------------- */
 int asm_device_malloc(asm_handle* h, size_t bytes, void** d_ptr);
 int asm_device_free(asm_handle* h, void* d_ptr);

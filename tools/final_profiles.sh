@@ -11,7 +11,7 @@ echo "pmc_sq done"
 bash $R/tools/pmc_traffic.sh 5 > $O/pmc_traffic.txt 2>&1
 echo "pmc_traffic done"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o c2 -- python3 $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $O/stats_bench.json 2> $O/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o c2 -- python3 $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-standalone > $O/stats_bench.json 2> $O/stats.err
 echo "kernel stats done"
 cd $R
 python3 bench.py > $O/bench.json 2> $O/bench.err
