@@ -528,3 +528,27 @@ def test_greedy_semi_global(asm, engine, oracle, wl, n, k, pen):
         assert cig == want_cig
     with pytest.raises(asm.AsmError):
         engine.align(batch, asm.GREEDY, asm.Params.default(k=k, alignment_type=2))
+
+
+def test_profile_events_inside_run_benchmark(asm, engine):
+    """asm_profile_enable / asm_profile_read: per-kernel HIP events recorded by the library inside asm_run_benchmark_async
+    (what bench.py uses for the dominant kernel's duration inside its timed region)."""
+    cfg, _, params = asm.workload("C2")
+    n = 200_000
+    batch = engine.generate(cfg, 0, n)
+    d = [engine.malloc(4 * n) for _ in range(3)]
+    d_cnt = engine.malloc(32)
+    engine.memset_async(d_cnt, 0, 32)
+    for mask, want in ((0xF, [True] * 4), (0x8, [False, False, False, True])):
+        engine.profile_enable(3, mask)
+        for _ in range(5):  # only the first three calls are recorded
+            engine.run_benchmark_async(batch, params, d[0], d[1], d[2], d_cnt, repack=True)
+        ms = engine.profile_read(8)
+        assert ms.shape == (3, 4)
+        for q in range(4):
+            assert ((ms[:, q] > 0) & (ms[:, q] < 50)).all() if want[q] else (ms[:, q] == -1).all(), (mask, q, ms)
+    engine.profile_enable(0, 0)
+    engine.run_benchmark_async(batch, params, d[0], d[1], d[2], d_cnt, repack=True)
+    assert engine.profile_read(8).shape[0] == 0
+    for x in d + [d_cnt]:
+        engine.free(x)
