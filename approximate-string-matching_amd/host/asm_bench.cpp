@@ -2,6 +2,8 @@
 // generate (or read) a ">read\n<ref\n" file, run NW + LEAP + Greedy over it, print the results block.
 //   asm-bench [--file path | --n N --len L --err E --seed S] [--k K --x X --o O --e E] [--mode sequential|clean]
 //             [--answers path]
+//   asm-bench --pair READ REF [--k K]                                     the per-pair classes of the reference on one pair
+//                                                                        (hurdle_matrix reset/run/get_cost/get_CIGAR, LV, SIMD_ED)
 //   asm-bench --leap-simd ERROR [--shd 0|1] [--batch-run N] < pairs      the LEAP_SIMD stdin filter driver
 //                                                                        (GASMA/benchmark/LEAP_SIMD/main.cpp:52-101)
 #include <cstdlib>
@@ -14,6 +16,8 @@ int main(int argc, char** argv) {
     using namespace asm_amd;
     std::string file, answers, mode = "sequential";
     int leap_simd = -1, shd = 1;
+    std::string pair_read, pair_ref;
+    bool pair_mode = false;
     long batch_run = 1000000;
     int n = 1000000, len = 100, k = 3, x = 1, o = 1, e = 1;
     float err = 0.10f;
@@ -31,6 +35,7 @@ int main(int argc, char** argv) {
         else if (arg("--o")) o = atoi(argv[++i]);
         else if (arg("--e")) e = atoi(argv[++i]);
         else if (arg("--mode")) mode = argv[++i];
+        else if (!strcmp(argv[i], "--pair") && i + 2 < argc) pair_mode = true, pair_read = argv[++i], pair_ref = argv[++i];
         else if (arg("--leap-simd")) leap_simd = atoi(argv[++i]);
         else if (arg("--shd")) shd = atoi(argv[++i]);
         else if (arg("--batch-run")) batch_run = atol(argv[++i]);
@@ -41,6 +46,27 @@ int main(int argc, char** argv) {
     }
     try {
         if (leap_simd >= 0) return leap_simd_filter(stdin, leap_simd, shd != 0, batch_run);
+        if (pair_mode) {  // GASMA/main.cpp:5-17 in the reference's own vocabulary
+            hurdle_matrix<int_128bit> greedy(GLOBAL, x, o, e);
+            greedy.reset(pair_read.c_str(), pair_ref.c_str(), k);
+            greedy.run();
+            printf("greedy cost %d CIGAR %s\n", greedy.get_cost(), greedy.get_CIGAR().c_str());
+            LV lv;
+            lv.init(k, 200, ED_GLOBAL, x, o, e);
+            const int length = (int)(pair_read.size() > pair_ref.size() ? pair_read.size() : pair_ref.size());
+            lv.load_reads((char*)pair_read.c_str(), (char*)pair_ref.c_str(), length);
+            lv.reset();
+            lv.run();
+            printf("leap pass %d ED %d\n", lv.check_pass() ? 1 : 0, lv.get_ED());
+            SIMD_ED sed;
+            sed.init_levenshtein(k, ED_GLOBAL, true);
+            sed.load_reads((char*)pair_read.c_str(), (char*)pair_ref.c_str(), (int)pair_read.size());
+            sed.calculate_masks();
+            sed.reset();
+            sed.run();
+            printf("simd_ed pass %d ED %d\n", sed.check_pass() ? 1 : 0, sed.get_ED());
+            return 0;
+        }
         if (file.empty()) {
             Dataset dataset(n, len, err, 0.96f, true, seed);  // benchmark.cpp:19
             file = dataset.output();

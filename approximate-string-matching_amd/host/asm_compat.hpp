@@ -1,6 +1,6 @@
 // Header-only C++ host side over the C ABI (include/asm_mi355x.h), mirroring the reference's interface for the
 // hot path so that code written against the reference reads the same:
-//   hurdle_matrix<T>  reset/run/get_cost           GASMA/hurdle_matrix.h:552-562,568,625,667,677
+//   hurdle_matrix<T>  reset/run/get_cost/get_CIGAR GASMA/hurdle_matrix.h:552-562,568,613,625,667,677
 //   LV                init/load_reads/reset/run/check_pass/get_ED   GASMA/benchmark/LEAP_SIMD/LV_BAG.h:40-54
 //   benchmark         read_string_file/read_answer_file/run/print   GASMA/benchmark/benchmark_utils.h:263-402
 //   Dataset           output()                                       GASMA/benchmark/benchmark_dataset.h:189-253
@@ -49,7 +49,7 @@ inline int align_one(int aligner, const char* read, int m, const char* ref, int 
 template <typename T = int_128bit>
 class hurdle_matrix {
     asm_params p_;
-    std::string read_, ref_;
+    std::string read_, ref_, cigar_;
     int cost_ = 0;
 
 public:
@@ -68,8 +68,36 @@ public:
     }
     void reset(const char* read, const char* ref, int error) { reset(read, (int)strlen(read), ref, (int)strlen(ref), error); }
     // A lone object has no batch history: tails are clean (the reference's are indeterminate for a first pair).
-    void run() { cost_ = align_one(ASM_GREEDY, read_.data(), (int)read_.size(), ref_.data(), (int)ref_.size(), p_, ASM_GREEDY_CLEAN); }
+    // cost and CIGAR in one device call (hurdle_matrix.h:568-597,613,677)
+    void run() {
+        asm_handle* h = shared_handle();
+        uint32_t ro[2] = {0u, (uint32_t)read_.size()}, fo[2] = {0u, (uint32_t)ref_.size()};
+        const int cap = 192;
+        asm_batch* b = nullptr;
+        void *d_cost = nullptr, *d_ops = nullptr, *d_nops = nullptr;
+        check(h, asm_batch_upload(h, 1, read_.data(), ro, ref_.data(), fo, ASM_GREEDY_CLEAN, &b));
+        check(h, asm_device_malloc(h, sizeof(int32_t), &d_cost));
+        check(h, asm_device_malloc(h, sizeof(uint16_t) * cap, &d_ops));
+        check(h, asm_device_malloc(h, 1, &d_nops));
+        const int rc = asm_greedy_cigar_batch_async(h, b, &p_, (int32_t*)d_cost, (uint16_t*)d_ops, cap, (uint8_t*)d_nops);
+        uint16_t ops[192];
+        uint8_t nops = 0;
+        int32_t cost = 0;
+        if (rc == ASM_OK) {
+            check(h, asm_memcpy_d2h(h, &cost, d_cost, sizeof cost));
+            check(h, asm_memcpy_d2h(h, ops, d_ops, sizeof ops));
+            check(h, asm_memcpy_d2h(h, &nops, d_nops, 1));
+        }
+        asm_device_free(h, d_cost), asm_device_free(h, d_ops), asm_device_free(h, d_nops);
+        asm_batch_free(h, b);
+        check(h, rc);
+        cost_ = cost;
+        char text[1024];
+        check(h, asm_cigar_format(ops, nops, cap, text, sizeof text));
+        cigar_ = text;
+    }
     int get_cost() const { return cost_; }
+    std::string get_CIGAR() const { return cigar_; }
 };
 
 class LV {

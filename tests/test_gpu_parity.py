@@ -552,3 +552,26 @@ def test_profile_events_inside_run_benchmark(asm, engine):
     assert engine.profile_read(8).shape[0] == 0
     for x in d + [d_cnt]:
         engine.free(x)
+
+
+def test_per_pair_classes_of_the_reference(asm, oracle):
+    """host/asm_compat.hpp's hurdle_matrix (reset/run/get_cost/get_CIGAR), LV and SIMD_ED on single pairs, through
+    `asm-bench --pair`: the demo pair of GASMA/main.cpp:7-8 gives 22M1D50M1D28M at cost 6; everything equals the oracle."""
+    import json
+    import os
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(asm.LIB_PATH), "asm-bench")
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "index.json")))["known_answers"]
+    for key in ("KA-0", "KA-5", "KA-6"):
+        a, b = KNOWN_PAIRS[key]
+        out = subprocess.check_output([exe, "--pair", a, b, "--k", "3"], text=True).splitlines()
+        hb = asm.HostBatch.from_strings([(a, b)])
+        cost, cig = oracle.greedy(hb, k=3, mode=1, cigars=True)
+        assert out[0] == "greedy cost %d CIGAR %s" % (int(cost[0]), cig[0]), (key, out[0])
+        if key == "KA-0":
+            assert out[0] == "greedy cost 6 CIGAR 22M1D50M1D28M" == "greedy cost %d CIGAR %s" % (gold[key]["greedy_k3"], gold[key]["greedy_cigar_k3"])
+        leap = int(oracle.leap(hb, k=3)[0])
+        assert out[1] == "leap pass %d ED %d" % (1 if leap >= 0 else 0, leap), (key, out[1])
+        ed, _, ps = oracle.simd_ed(hb, 3, True, 0, (0, 0, 0))
+        assert out[2] == "simd_ed pass %d ED %d" % (int(ps[0]), int(ed[0])), (key, out[2])
