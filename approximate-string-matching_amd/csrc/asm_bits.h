@@ -69,6 +69,26 @@ ASM_DEV int v_next_one_after_zero_run(V128 l, int fz) {
     return p == 128 ? 128 : p - fz;
 }
 
+// first set bit at index >= from, 128 when there is none (or from >= 128): only the word `from` falls into is shifted
+ASM_DEV int v_next_one_from(V128 v, int from) {
+    const bool low = from < 64;
+    const u64 y = (low ? v.lo : v.hi) >> (from & 63);
+    int res = (low && v.hi) ? 64 + __builtin_ctzll(v.hi) : 128;
+    if (y) res = from + __builtin_ctzll(y);
+    return from >= 128 ? 128 : res;
+}
+
+// The next highway of a (flipped) lane vector at or after column `start` (hurdle_matrix.h:299-303):
+//   l = shift_left(v, start); fz = first_zero(l); nx = first_one(shift_left(l, fz))
+// as two forward scans on the unshifted vector: a0 = first zero at or after start (128 when none: the zeros that the
+// shift brings in at the top), a1 = first one after it.  start >= 128 is the empty shifted vector (fz = 0, nx = 128).
+ASM_DEV void v_highway_from(V128 v, int start, int& fz, int& nx) {
+    const int a0 = v_next_one_from(v_not(v), start);
+    const int a1 = v_next_one_from(v, a0);
+    fz = (unsigned)start >= 128u ? 0 : a0 - start;
+    nx = a1 == 128 ? 128 : a1 - a0;
+}
+
 ASM_DEV int v_popcount(V128 v) { return __popcll(v.lo) + __popcll(v.hi); }
 
 // ones at index >= s (any s >= 0; 0 from 128 on).  A popcount does not care where the surviving bits end up, so instead of

@@ -317,9 +317,8 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_kernel(const uint4* __restri
             if (sp[j] < start_col) {
                 int d = lane - cur_lane;
                 nsw[j] = d < 0 ? -d : d;
-                const V128 l = v_toward0(lf_[j], start_col);
-                const int fz = v_first_zero(l);
-                const int nx = v_next_one_after_zero_run(l, fz);
+                int fz, nx;
+                v_highway_from(lf_[j], start_col, fz, nx);
                 sp[j] = start_col + fz;
                 len[j] = nx;
                 if (start_col + fz + nx > dst[j]) {
@@ -530,9 +529,8 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_persist_kernel(const uint4* 
                 if (sp[j] < start_col) {
                     int d = lane - cur_lane;
                     nsw[j] = d < 0 ? -d : d;
-                    const V128 l = v_toward0(lf_[j], start_col);
-                    const int fz = v_first_zero(l);
-                    const int nx = v_next_one_after_zero_run(l, fz);
+                    int fz, nx;
+                    v_highway_from(lf_[j], start_col, fz, nx);
                     sp[j] = start_col + fz;
                     len[j] = nx;
                     if (start_col + fz + nx > dst[j]) {

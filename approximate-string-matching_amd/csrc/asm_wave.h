@@ -393,9 +393,8 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_wave_kernel(const uint4* __r
                 if (sp < start_col) {
                     const int dd = lane - cur_lane;
                     nsw = dd < 0 ? -dd : dd;
-                    const V128 l = v_toward0(lf_, start_col);
-                    const int fz = v_first_zero(l);
-                    const int nx = v_next_one_after_zero_run(l, fz);
+                    int fz, nx;
+                    v_highway_from(lf_, start_col, fz, nx);
                     sp = start_col + fz;
                     len = nx;
                     if (start_col + fz + nx > dst) {
@@ -527,9 +526,8 @@ __global__ __launch_bounds__(GREEDY_WAVE2_THREADS) void greedy_wave2_kernel(cons
                 if (sp < start_col) {
                     const int dd = lane - cur_lane;
                     nsw = dd < 0 ? -dd : dd;
-                    const V128 l = v_toward0(lf_, start_col);
-                    const int fz = v_first_zero(l);
-                    const int nx = v_next_one_after_zero_run(l, fz);
+                    int fz, nx;
+                    v_highway_from(lf_, start_col, fz, nx);
                     sp = start_col + fz;
                     len = nx;
                     if (start_col + fz + nx > dst) {

@@ -172,9 +172,8 @@ __global__ __launch_bounds__(ASM_WIDE_THREADS) void greedy_wide_kernel(const uin
                 if (sp < start_col) {
                     int dd = lane - cur_lane;
                     nsw = dd < 0 ? -dd : dd;
-                    const V128 l = v_toward0(lf_, start_col);
-                    const int fz = v_first_zero(l);
-                    const int nx = v_first_one(v_toward0(l, fz));
+                    int fz, nx;
+                    v_highway_from(lf_, start_col, fz, nx);
                     sp = start_col + fz;
                     len = nx;
                     if (start_col + fz + nx > dst) {
