@@ -10,6 +10,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    # The checker libraries must exist before collection: test modules decide at import time whether the compiled reference
+    # (oracle/_ref, buildable only where /root/reference exists) is there.  `make` is a no-op when everything is up to date.
+    import subprocess
+
+    try:
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=False, capture_output=True, timeout=600)
+    except (OSError, subprocess.TimeoutExpired):
+        pass
 
 
 @pytest.fixture(scope="session")
