@@ -113,6 +113,7 @@ def load_library() -> ctypes.CDLL:
         "asm_destroy": (i32, [vp]),
         "asm_last_error": (c.c_char_p, [vp]),
         "asm_set_stream": (i32, [vp, vp]),
+        "asm_reset_stream": (i32, [vp]),
         "asm_synchronize": (i32, [vp]),
         "asm_generate_pairs": (i32, [c.POINTER(GenConfig), i64, i64, vp, vp, vp, c.c_size_t, vp, c.c_size_t]),
         "asm_batch_upload": (i32, [vp, i64, vp, vp, vp, vp, i32, c.POINTER(vp)]),
@@ -317,7 +318,12 @@ class Engine:
             pass
 
     def set_stream(self, hip_stream: Optional[int]) -> None:
-        self._chk(self.lib.asm_set_stream(self.h, hip_stream))
+        """Launch on a caller-owned hipStream_t.  0/None is HIP's legacy default stream (torch's `current_stream().cuda_stream`
+        outside a stream context), not "the engine's own stream" — that is `reset_stream()`."""
+        self._chk(self.lib.asm_set_stream(self.h, hip_stream or None))
+
+    def reset_stream(self) -> None:
+        self._chk(self.lib.asm_reset_stream(self.h))
 
     def synchronize(self) -> None:
         self._chk(self.lib.asm_synchronize(self.h))

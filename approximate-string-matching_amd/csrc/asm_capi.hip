@@ -322,7 +322,16 @@ const char* asm_last_error(const asm_handle* h) { return h ? h->err.c_str() : g_
 
 int asm_set_stream(asm_handle* h, void* hip_stream) {
     if (!h) return fail(nullptr, ASM_EINVAL, "asm_set_stream: NULL handle");
-    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    /* NULL is HIP's legacy default stream (what torch.cuda.current_stream().cuda_stream is outside a stream context): work is
+     * then ordered with everything else the caller enqueues there.  The handle's own stream is non-blocking — it never
+     * synchronises with the legacy stream — so it is only restored on request (asm_reset_stream). */
+    h->stream = (hipStream_t)hip_stream;
+    return ASM_OK;
+}
+
+int asm_reset_stream(asm_handle* h) {
+    if (!h) return fail(nullptr, ASM_EINVAL, "asm_reset_stream: NULL handle");
+    h->stream = h->own_stream;
     return ASM_OK;
 }
 
@@ -830,7 +839,7 @@ int asm_batch_download(asm_handle* h, const asm_batch* b, uint32_t* read_off, ui
 }
 
 /* ---------------------------------------------------------------------------------------------------- */
-static int check_params(asm_handle* h, int aligner, const asm_params* p) {
+static int check_params(asm_handle* h, int aligner, const asm_params* p, int maxlen = ASM_MAX_LENGTH) {
     if (!p) return fail(h, ASM_EINVAL, "params is NULL");
     if (p->x < 0 || p->o < 0 || p->e < 0) return fail(h, ASM_EINVAL, "penalties must be non-negative");
     if (aligner == ASM_GREEDY) {
@@ -846,7 +855,14 @@ static int check_params(asm_handle* h, int aligner, const asm_params* p) {
             return fail(h, ASM_EINVAL, "LEAP: need x >= 1, o >= e >= 1 (LV_BAG.cpp:165-166)");
         if (p->x > ASM_WIDE_MAX_PENALTY || p->o > ASM_WIDE_MAX_PENALTY)
             return fail(h, ASM_EUNSUPPORTED, "LEAP: penalties above the compiled history depth");
-    } else if (aligner != ASM_NW) {
+    } else if (aligner == ASM_NW) {
+        /* nw_affine_kernel keeps H/E/F below NW_BIG (int16 halves of one dword at the block boundary): every cell is at most
+         * gap(i) + gap(j), and E/F one gap-open above that */
+        const long worst = 2L * ((long)p->o + (long)(maxlen > 0 ? maxlen - 1 : 0) * (long)p->e) + (long)p->o;
+        if (p->x > 10000 || p->o > 10000 || p->e > 10000 || worst >= (long)NW_BIG)
+            return fail(h, ASM_EUNSUPPORTED, "NW: penalties too large for this batch's longest sequence "
+                                             "(need 2*(o + (maxlen-1)*e) + o < 30000 and x, o, e <= 10000)");
+    } else {
         return fail(h, ASM_EINVAL, "unknown aligner id");
     }
     return ASM_OK;
@@ -972,7 +988,9 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
                 hipLaunchKernelGGL((nw_banded_kernel<16, 64>), g, t, 0, h->stream, planes, lens, n, b.w4, out);
         } else {
             const RingGeometry rg(p->x, p->o, p->e);
-            if (h->nw_wfa && b.maxlen <= 256 && rg.lds_bytes(2 * NW_WFA_K + 1, LEAP_GEN_THREADS) <= 64 * 1024) {
+            /* a zero penalty makes the wavefront read the generation it is writing (ring slot s - 0): plain Gotoh handles it */
+            const bool positive = p->x >= 1 && p->o >= 1 && p->e >= 1;
+            if (h->nw_wfa && positive && b.maxlen <= 256 && rg.lds_bytes(2 * NW_WFA_K + 1, LEAP_GEN_THREADS) <= 64 * 1024) {
                 const int rc = b.maxlen <= 128 ? launch_nw_wfa<2, 128>(h, b, p, out) : launch_nw_wfa<4, 256>(h, b, p, out);
                 if (rc != ASM_OK) return rc;
             } else {
@@ -987,7 +1005,7 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
 int asm_align_batch_hinted_async(asm_handle* h, const asm_batch* b, int aligner, const asm_params* p,
                                  const int32_t* d_work_hint, int32_t* d_penalties) {
     if (!h || !b || !d_penalties) return fail(h, ASM_EINVAL, "asm_align_batch_hinted_async: NULL argument");
-    int rc = check_params(h, aligner, p);
+    int rc = check_params(h, aligner, p, b->maxlen);
     if (rc) return rc;
     if (b->n == 0) return ASM_OK;
     HIPCHK(h, hipSetDevice(h->device));
@@ -1002,7 +1020,7 @@ int asm_align_batch_hinted_async(asm_handle* h, const asm_batch* b, int aligner,
 
 int asm_align_batch_async(asm_handle* h, const asm_batch* b, int aligner, const asm_params* p, int32_t* d_penalties) {
     if (!h || !b || !d_penalties) return fail(h, ASM_EINVAL, "asm_align_batch_async: NULL argument");
-    int rc = check_params(h, aligner, p);
+    int rc = check_params(h, aligner, p, b->maxlen);
     if (rc) return rc;
     if (b->n == 0) return ASM_OK;
     HIPCHK(h, hipSetDevice(h->device));

@@ -58,7 +58,9 @@ typedef struct asm_batch asm_batch;   /* a device-resident batch of read pairs (
  * and of hurdle_matrix (hurdle_matrix.h:552-559). */
 typedef struct asm_params {
     int32_t k;           /* band half-width (lanes -k..k)                                                 */
-    int32_t x, o, e;     /* mismatch, gap-open (first gap base), gap-extend penalties, all >= 0           */
+    int32_t x, o, e;     /* mismatch, gap-open (first gap base), gap-extend penalties.  NW: all >= 0, and small enough for
+                            the batch: 2*(o + (maxlen-1)*e) + o < 30000 (else ASM_EUNSUPPORTED).  LEAP: x >= 1,
+                            15 >= o >= e >= 1 (LV_BAG.cpp:165-166).  Greedy: >= 0                                       */
     double p_match;      /* Greedy significance model; defaults 0.80, 0.20/3, 0.40/3                      */
     double p_mismatch;
     double p_indel;
@@ -77,9 +79,13 @@ int asm_device_count(void);                       /* number of HIP devices (0 wi
 int asm_create(asm_handle** out, int device);     /* binds the handle to HIP device `device`               */
 int asm_destroy(asm_handle* h);
 const char* asm_last_error(const asm_handle* h);  /* h may be NULL: last error of the calling thread       */
-/* Launch everything on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the
+/* Launch everything on a caller-owned hipStream_t (e.g. torch's current stream).  NULL is HIP's legacy default stream —
+ * which is what torch hands out outside a `torch.cuda.stream(...)` context — NOT "no stream": the handle's own stream is
+ * non-blocking and never synchronises with the legacy one, so a caller that mixes its own work (a collective, a torch op
+ * on d_penalties) with this library's must put both on one stream through this call.  asm_reset_stream goes back to the
  * handle's own stream. */
 int asm_set_stream(asm_handle* h, void* hip_stream);
+int asm_reset_stream(asm_handle* h);
 int asm_synchronize(asm_handle* h);
 
 /* ---- input definition: seeded restatement of `Dataset` (benchmark_dataset.h:61-253) ---- */

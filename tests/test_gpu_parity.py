@@ -117,6 +117,31 @@ def test_affine_nw_wavefront_pass_and_full_matrix_fallback(asm, engine, oracle, 
     _check("nw ragged", engine.align(batch, asm.NW, asm.Params.default(x=x, o=o, e=e)), oracle.nw(hb, x, o, e), hb)
 
 
+@pytest.mark.parametrize("x,o,e", [(1, 1, 0), (0, 2, 1), (1, 0, 1), (0, 0, 0), (3, 0, 0), (40, 50, 20)])
+def test_nw_zero_and_large_penalties(asm, engine, oracle, x, o, e):
+    """A zero among (x, o, e) must not go through the wavefront kernel (its ring would read the generation being written):
+    plain Gotoh handles it.  Penalties that would saturate the 16-bit boundary cells are refused, not truncated."""
+    cfg, _, _ = asm.workload("C2")
+    hb = asm.generate_pairs(cfg, 29, 2000)
+    batch = engine.upload(hb, asm.GREEDY_CLEAN)
+    _check(f"nw ({x},{o},{e})", engine.align(batch, asm.NW, asm.Params.default(x=x, o=o, e=e)), oracle.nw(hb, x, o, e), hb)
+    hb = random_ragged_batch(asm, 37, 800, 0, 250)
+    batch = engine.upload(hb, asm.GREEDY_CLEAN)
+    _check(f"nw ragged ({x},{o},{e})", engine.align(batch, asm.NW, asm.Params.default(x=x, o=o, e=e)), oracle.nw(hb, x, o, e), hb)
+
+
+def test_nw_penalties_beyond_the_cell_width_are_refused(asm, engine):
+    hb = asm.HostBatch.from_strings([("ACGT" * 100, "ACGA" * 100)])
+    batch = engine.upload(hb, asm.GREEDY_CLEAN)
+    for x, o, e in ((1, 1, 40), (1, 20000, 1), (20000, 1, 1)):
+        with pytest.raises(asm.AsmError) as ei:
+            engine.align(batch, asm.NW, asm.Params.default(x=x, o=o, e=e))
+        assert ei.value.code == -4
+    # the same extension penalty is fine on a short batch
+    short = engine.upload(asm.HostBatch.from_strings([("ACGTACGT", "ACGACGT")]), asm.GREEDY_CLEAN)
+    assert engine.align(short, asm.NW, asm.Params.default(x=1, o=1, e=40)).tolist() == [1]
+
+
 @pytest.mark.parametrize("x,o,e", [(1, 1, 1), (2, 3, 1)])
 def test_ragged_and_edge_lengths(asm, engine, oracle, x, o, e):
     """Empty strings, 1, 63/64/65, 127/128/129, 255/256/257, 300 and random lengths in one batch."""
