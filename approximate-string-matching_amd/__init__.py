@@ -122,6 +122,9 @@ def load_library() -> ctypes.CDLL:
         "asm_reference_free": (i32, [vp, vp]),
         "asm_batch_from_hits": (i32, [vp, vp, i64, vp, vp, vp, i32, c.POINTER(vp)]),
         "asm_batch_free": (i32, [vp, vp]),
+        "asm_batch_tail_summary": (i32, [vp, vp, vp]),
+        "asm_tail_state_advance": (i32, [vp, vp, i64]),
+        "asm_batch_resolve_tails": (i32, [vp, vp, vp]),
         "asm_batch_size": (i64, [vp]),
         "asm_batch_max_length": (i32, [vp]),
         "asm_batch_download": (i32, [vp, vp, vp, vp, vp, c.c_size_t, vp, c.c_size_t]),
@@ -362,6 +365,21 @@ class Engine:
                                                pos.ctypes.data, greedy_mode, ctypes.byref(ptr)))
         return DeviceBatch(self, ptr)
 
+    # ---- Greedy's sequential mode across batches (shards of one file / chunks of a stream) ----
+    def tail_summary(self, batch: DeviceBatch) -> np.ndarray:
+        """asm_batch_tail_summary: uint8[256], what this batch does to the reference's two persistent buffers."""
+        out = np.zeros(256, np.uint8)
+        self._chk(self.lib.asm_batch_tail_summary(self.h, batch.ptr, out.ctypes.data))
+        return out
+
+    def resolve_tails(self, batch: DeviceBatch, state: Optional[np.ndarray] = None) -> None:
+        """asm_batch_resolve_tails: make `batch` a sequential-mode batch whose first pair sees `state` (uint8[256] of 2-bit
+        codes; None = a file's start) in the buffers."""
+        st = None if state is None else np.ascontiguousarray(state, np.uint8)
+        if st is not None and st.size != 256:
+            raise ValueError("state must have 256 entries")
+        self._chk(self.lib.asm_batch_resolve_tails(self.h, batch.ptr, None if st is None else st.ctypes.data))
+
     def pack_async(self, batch: DeviceBatch) -> None:
         self._chk(self.lib.asm_batch_pack_async(self.h, batch.ptr))
 
@@ -577,6 +595,37 @@ def shard_bounds(total: int, world: int, rank: int) -> Tuple[int, int]:
 def weak_shard_first(rank: int, pairs_per_rank: int) -> int:
     """Weak scaling: rank r owns pairs [r*n, (r+1)*n) of the seeded stream."""
     return rank * pairs_per_rank
+
+
+def tail_state_advance(state: np.ndarray, summary: np.ndarray, n_pairs: int) -> np.ndarray:
+    """asm_tail_state_advance (host only, needs no GPU): buffer state after a batch of n_pairs with the given summary."""
+    lib = load_library()
+    st = np.ascontiguousarray(state, np.uint8).copy()
+    sm = np.ascontiguousarray(summary, np.uint8)
+    rc = lib.asm_tail_state_advance(st.ctypes.data, sm.ctypes.data, int(n_pairs))
+    if rc:
+        raise AsmError(rc, lib.asm_last_error(None).decode())
+    return st
+
+
+def chain_tail_state(summary: np.ndarray, n_pairs: int, dist=None, device=None) -> np.ndarray:
+    """The buffer state before THIS rank's shard of a file whose shards are laid out in rank order: one all-gather of every
+    shard's 256-byte summary and size (the only exchange sequential mode needs), then a local fold over the shards before
+    ours.  Rank 0, or no process group: zeros — a file's start (hurdle_matrix.h:136-137)."""
+    state = np.zeros(256, np.uint8)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return state
+    import torch
+
+    mine = torch.zeros(264, dtype=torch.uint8, device=device)
+    mine[:256] = torch.from_numpy(np.ascontiguousarray(summary, np.uint8)).to(mine.device)
+    mine[256:] = torch.from_numpy(np.frombuffer(np.int64(n_pairs).tobytes(), np.uint8).copy()).to(mine.device)
+    parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    for r in range(dist.get_rank()):
+        row = parts[r].cpu().numpy()
+        state = tail_state_advance(state, row[:256], int(np.frombuffer(row[256:].tobytes(), np.int64)[0]))
+    return state
 
 
 def allreduce_counters(counters, dist=None):

@@ -446,11 +446,14 @@ int asm_batch_pack_async(asm_handle* h, asm_batch* b) {
 }
 
 /* ASM_GREEDY_SEQUENTIAL: derive the stale buffer tails on the device (asm_tails.h).  The resolver walks the pairs
- * in INPUT order and only needs granule 0, so it works on a temporary clean-mode, unbucketed, one-granule packing. */
-static int batch_resolve_tails(asm_handle* h, asm_batch* b) {
+ * in INPUT order and only needs granule 0, so it works on a temporary clean-mode, unbucketed, one-granule packing.
+ * init256 (host, optional): buffer codes before the batch's first pair; summary256 (host, optional): the batch's effect on
+ * the buffers (see tails_carry_kernel); emit = false stops after the summary (b->d_tails untouched). */
+static int batch_resolve_tails(asm_handle* h, asm_batch* b, const uint8_t* init256, uint8_t* summary256, bool emit) {
+    if (summary256) memset(summary256, TAIL_NONE, 256);
     if (b->n == 0) return ASM_OK;
     const long nchunks = (b->n + TAIL_CHUNK - 1) / TAIL_CHUNK;
-    uint8_t *d_last = nullptr, *d_carry = nullptr;
+    uint8_t *d_last = nullptr, *d_carry = nullptr, *d_state = nullptr;
     uint4* d_g0 = nullptr;
     uint32_t* d_l0 = nullptr;
     int rc = ASM_OK;
@@ -460,25 +463,31 @@ static int batch_resolve_tails(asm_handle* h, asm_batch* b) {
         rc = fail(h, ASM_ENODEVICE, std::string(#call) + " failed");     \
         break;                                                           \
     }
-        TRY(hipMalloc((void**)&b->d_tails, sizeof(uint4) * 4 * (size_t)b->n));
+        if (emit && !b->d_tails) TRY(hipMalloc((void**)&b->d_tails, sizeof(uint4) * 4 * (size_t)b->n));
         TRY(hipMalloc((void**)&d_g0, sizeof(uint4) * 4 * (size_t)b->n));
         TRY(hipMalloc((void**)&d_l0, sizeof(uint32_t) * (size_t)b->n));
         TRY(hipMalloc((void**)&d_last, (size_t)nchunks * 256));
         TRY(hipMalloc((void**)&d_carry, (size_t)nchunks * 256));
+        TRY(hipMalloc((void**)&d_state, 512)); /* [0,256) init, [256,512) summary */
+        if (init256) TRY(hipMemcpyAsync(d_state, init256, 256, hipMemcpyHostToDevice, h->stream));
         PackBuckets one{};
         one.nb = 1, one.w4[0] = 1, one.start[0] = 0, one.start[1] = b->n, one.plane_off[0] = 0;
         TRY(launch_pack(h, b, nullptr, d_g0, d_l0, one, nullptr));
         hipLaunchKernelGGL(tails_chunk_kernel, dim3((unsigned)nchunks), dim3(256), 0, h->stream, d_g0, d_l0, (long)b->n, 1,
                            d_last);
-        hipLaunchKernelGGL(tails_carry_kernel, dim3(1), dim3(256), 0, h->stream, d_last, d_carry, nchunks);
-        hipLaunchKernelGGL(tails_emit_kernel, dim3((unsigned)nchunks), dim3(256), 0, h->stream, d_g0, d_l0, (long)b->n, 1,
-                           d_carry, b->d_tails);
+        hipLaunchKernelGGL(tails_carry_kernel, dim3(1), dim3(256), 0, h->stream, d_last, d_carry, nchunks,
+                           (const uint8_t*)(init256 ? d_state : nullptr), summary256 ? d_state + 256 : (uint8_t*)nullptr);
+        if (emit)
+            hipLaunchKernelGGL(tails_emit_kernel, dim3((unsigned)nchunks), dim3(256), 0, h->stream, d_g0, d_l0, (long)b->n, 1,
+                               d_carry, b->d_tails);
         TRY(hipGetLastError());
+        if (summary256) TRY(hipMemcpyAsync(summary256, d_state + 256, 256, hipMemcpyDeviceToHost, h->stream));
         TRY(hipStreamSynchronize(h->stream));
 #undef TRY
     } while (0);
     (void)hipFree(d_last);
     (void)hipFree(d_carry);
+    (void)hipFree(d_state);
     (void)hipFree(d_g0);
     (void)hipFree(d_l0);
     return rc;
@@ -562,7 +571,7 @@ static int batch_finish(asm_handle* h, asm_batch* b) {
             b->bk[q].order = b->d_order ? b->d_order + b->pb.start[q] : nullptr;
         }
 #undef TRY
-        if (b->greedy_mode == ASM_GREEDY_SEQUENTIAL) rc = batch_resolve_tails(h, b);
+        if (b->greedy_mode == ASM_GREEDY_SEQUENTIAL) rc = batch_resolve_tails(h, b, nullptr, nullptr, true);
         if (rc) break;
         rc = asm_batch_pack_async(h, b);
         if (rc) break;
@@ -809,6 +818,39 @@ int asm_batch_from_hits(asm_handle* h, const asm_reference* ref, int64_t n, cons
     }
     *out = b;
     return ASM_OK;
+}
+
+/* ---- Greedy sequential mode across batches: shards of one file on several GPUs, or chunks of a streamed file ---- */
+int asm_batch_tail_summary(asm_handle* h, const asm_batch* b, uint8_t* summary) {
+    if (!h || !b || !summary) return fail(h, ASM_EINVAL, "asm_batch_tail_summary: NULL argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    return batch_resolve_tails(h, const_cast<asm_batch*>(b), nullptr, summary, false);
+}
+
+int asm_tail_state_advance(uint8_t* state, const uint8_t* summary, int64_t n_pairs) {
+    if (!state || !summary || n_pairs < 0) return fail(nullptr, ASM_EINVAL, "asm_tail_state_advance: bad argument");
+    uint8_t next[256];
+    for (int side = 0; side < 2; side++)
+        for (int s = 0; s < 128; s++) {
+            const uint8_t w = summary[side * 128 + s];
+            if (w != TAIL_NONE && w > 3) return fail(nullptr, ASM_EINVAL, "asm_tail_state_advance: summary entries are 0..3 or 0xFF");
+            next[side * 128 + tail_slot_after(s, (long long)n_pairs)] = w != TAIL_NONE ? w : state[side * 128 + s];
+        }
+    memcpy(state, next, 256);
+    return ASM_OK;
+}
+
+int asm_batch_resolve_tails(asm_handle* h, asm_batch* b, const uint8_t* state) {
+    if (!h || !b) return fail(h, ASM_EINVAL, "asm_batch_resolve_tails: NULL argument");
+    if (state)
+        for (int q = 0; q < 256; q++)
+            if (state[q] > 3) return fail(h, ASM_EINVAL, "asm_batch_resolve_tails: state entries are 2-bit codes (0..3)");
+    HIPCHK(h, hipSetDevice(h->device));
+    b->greedy_mode = ASM_GREEDY_SEQUENTIAL;
+    int rc = batch_resolve_tails(h, b, state, nullptr, true);
+    if (!rc) rc = asm_batch_pack_async(h, b);
+    if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(h, ASM_ENODEVICE, "asm_batch_resolve_tails: stream synchronize failed");
+    return rc;
 }
 
 int asm_batch_free(asm_handle* h, asm_batch* b) {

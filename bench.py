@@ -9,12 +9,19 @@ device from the seeded stream (rank r owns pairs [r*n, (r+1)*n)) — inputs are 
 region.  Pairs are independent, so ranks share nothing on the data path (weak scaling); one RCCL all-reduce of the
 four int64 counters {total, nw_ok, leap_ok, greedy_ok} closes the timed region.
 
+Launch: one process per GPU.  Under torchrun (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`)
+the ranks come from the environment; a plain `python bench.py --gpus N` starts the N ranks itself (fresh child
+processes, created before this process has touched a GPU) and relays rank 0's line.
+
 Prints ONE JSON line on rank 0 (see the contract in the task statement) with `roofline` for the dominant kernel and
 `cpu_baseline` (the oracle = CPU port of the reference, timed on this host's cores on a bounded sample).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,36 +31,79 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md §Chip-level parameters)
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+KERNEL_SOURCES = ("approximate-string-matching_amd/csrc", "approximate-string-matching_amd/Makefile")
 
 
-def pmc_traffic(kernel, pairs):
-    """HBM bytes per launch of `kernel` from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, collected offline with
-    tools/pmc_traffic.sh in separate rocprofv3 --pmc passes and committed as profiles/r01_pmc_traffic.json), scaled
-    to this launch's pair count.  None when no measurement is on file."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+def kernel_source_digest():
+    """sha256 over the kernel sources: the PMC file records the digest of the code it measured, so numbers from an older
+    kernel can never be quoted for the current one (round 1's stale `traffic`)."""
+    h = hashlib.sha256()
+    files = []
+    for rel in KERNEL_SOURCES:
+        path = os.path.join(ROOT, rel)
+        if os.path.isdir(path):
+            files += sorted(os.path.join(path, f) for f in os.listdir(path) if f.endswith((".h", ".hip")))
+        else:
+            files.append(path)
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc(workload):
+    """Counters collected by tools/pmc_collect.py (separate rocprofv3 --pmc passes over this very script).  Returns
+    (entry-per-kernel dict, meta) or (None, reason)."""
     try:
-        with open(path) as fh:
+        with open(PMC_FILE) as fh:
             d = json.load(fh)
-        return d["kernels"][kernel]["traffic_bytes"] * pairs / d["pairs"]
-    except (OSError, KeyError, ValueError):
-        return None
+    except (OSError, ValueError) as exc:
+        return None, f"no PMC file ({exc.__class__.__name__})"
+    if d.get("source_digest") != kernel_source_digest():
+        return None, f"{os.path.relpath(PMC_FILE, ROOT)} was measured on other kernel sources (digest {d.get('source_digest')})"
+    if d.get("workload") != workload:
+        return None, f"{os.path.relpath(PMC_FILE, ROOT)} holds workload {d.get('workload')}"
+    return d, None
 
 
-def valu_roofline(kernel, pairs, launch_ms):
-    """The roofline that actually bounds these kernels: VALU issue.  Instructions per launch come from the
-    SQ_INSTS_VALU counter (profiles/r01_pmc_valu.json, collected with tools/pmc_sq.sh); the ceiling is what the SIMDs can
-    issue for this instruction mix (measured ~4.3 cycles per wave-instruction, tools/ubench/valu_rates)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_valu.json")
-    try:
-        with open(path) as fh:
-            d = json.load(fh)
-        insts = d["kernels"][kernel]["insts_valu"] * pairs / d["pairs"]
-        peak = d["simd_count"] * d["nominal_clock_hz"] / d["cycles_per_inst_mix"]
-        achieved = insts / (launch_ms * 1e-3)
-        return {"bound": "valu-issue", "insts_per_launch": insts, "achieved": achieved, "peak": peak,
-                "unit": "wave-instructions/s", "frac": achieved / peak}
-    except (OSError, KeyError, ValueError):
+def pmc_for(pmc, short, pairs):
+    """The PMC entry of the kernel family `short` ("greedy", "nw", "leap", "pack"), scaled to this launch's pair count."""
+    if pmc is None:
         return None
+    k = pmc["kernels"].get(short)
+    if not k:
+        return None
+    scale = pairs / pmc["pairs"]
+    out = {"kernel_name": k["kernel_name"], "source": f"{os.path.relpath(PMC_FILE, ROOT)}@{pmc.get('git_head', '?')}"}
+    for key in ("traffic_bytes", "fetch_bytes", "write_bytes", "insts_valu", "active_inst_valu", "thread_cycles_valu"):
+        if k.get(key) is not None:
+            out[key] = k[key] * scale
+    return out
+
+
+def valu_roofline(entry, pmc, launch_ms):
+    """The roofline that actually bounds these kernels: VALU issue.  Wave-instructions per launch from
+    SQ_INSTS_VALU; two ceilings, both printed: the instruction mix as measured by tools/ubench/valu_rates on this chip
+    (cycles per wave-instruction per SIMD at the measured shader clock) and the architectural 2 cycles per wave64 VALU
+    instruction on a SIMD-32 at 2.4 GHz (MI355X_MICROARCH.md, row v_fma_f32).  lane_util = SQ_THREAD_CYCLES_VALU /
+    (64 * SQ_ACTIVE_INST_VALU): the share of the 64 lanes that did work in the issued instructions."""
+    if not entry or "insts_valu" not in entry:
+        return None
+    insts = entry["insts_valu"]
+    achieved = insts / (launch_ms * 1e-3)
+    simds = pmc.get("simd_count", 1024)
+    out = {"bound": "valu-issue", "insts_per_launch": insts, "achieved": achieved, "unit": "wave-instructions/s"}
+    mix = pmc.get("ubench", {})
+    if mix.get("cycles_per_inst_mix") and mix.get("sclk_hz"):
+        peak = simds * mix["sclk_hz"] / mix["cycles_per_inst_mix"]
+        out["peak_measured_mix"] = {"peak": peak, "frac": achieved / peak, "cycles_per_inst": mix["cycles_per_inst_mix"],
+                                    "sclk_hz": mix["sclk_hz"], "source": mix.get("source")}
+    peak2 = simds * 2.4e9 / 2.0
+    out["peak_arch_2cyc"] = {"peak": peak2, "frac": achieved / peak2}
+    if entry.get("thread_cycles_valu") and entry.get("active_inst_valu"):
+        out["lane_util"] = entry["thread_cycles_valu"] / (64.0 * entry["active_inst_valu"])
+    return out
 
 
 def algorithmic_bytes(m, n, aligners=1):
@@ -83,8 +133,7 @@ class QuietStdout:
         os.dup2(2, 1)
 
 
-def main():
-    quiet = QuietStdout()
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -98,7 +147,53 @@ def main():
     ap.add_argument("--no-standalone", action="store_true",
                     help="skip the separately instrumented stand-alone kernel pass (profiling runs: every launch is a timed-region launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-sequential", action="store_true", help="skip the Greedy sequential-mode (reference as run) leg")
+    return ap.parse_args()
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) and wait for them.  This
+    parent has not touched a GPU (no HIP call, no torch.cuda initialisation — counting devices does not initialise them), so
+    starting children is safe; rank 0 prints the JSON line on the stdout it inherits."""
+    rehearsal = os.environ.get("ASM_DIST_BACKEND", "nccl") != "nccl"  # gloo: several ranks may share the one visible GPU
+    import torch
+
+    have = torch.cuda.device_count()
+    if have < 1 or (have < args.gpus and not rehearsal):
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible")
+    env = dict(os.environ, WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(args.gpus):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r))))
+    code = 0
+    deadline = time.time() + 3000
+    for p in procs:
+        try:
+            rc = p.wait(timeout=max(deadline - time.time(), 1))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rc = 124
+        code = code or rc
+    if code:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    raise SystemExit(code)
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)
+    quiet = QuietStdout()
 
     import torch
 
@@ -107,23 +202,26 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (torchrun --nproc-per-node "
+                         f"{args.gpus}, or plain `python bench.py --gpus {args.gpus}` which starts the ranks itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
-    if os.environ.get("ASM_DIST_BACKEND", "nccl") != "nccl":
-        local_rank = local_rank % torch.cuda.device_count()  # rehearsal: several ranks share the one visible GPU
+    backend = os.environ.get("ASM_DIST_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm; gloo only to rehearse N>1 on a one-GPU box
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
+    elif torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1 or os.environ.get("ASM_FORCE_DIST") == "1":  # ASM_FORCE_DIST=1: exercise the RCCL path with one rank
+    if world > 1 or os.environ.get("ASM_FORCE_DIST") == "1":  # ASM_FORCE_DIST=1: exercise the collective path with one rank
         import torch.distributed as dist
 
-        # backend "nccl" IS RCCL on ROCm; ASM_DIST_BACKEND=gloo only to rehearse the N>1 code path on a one-GPU box
-        backend = os.environ.get("ASM_DIST_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+    coll_device = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
 
     cfg, n_default, params = asm.workload(args.workload)
     n = args.pairs or min(n_default, 1_000_000)
@@ -132,25 +230,37 @@ def main():
         lo, hi = asm.shard_bounds(args.total_pairs, world, rank)
         first, n = lo, hi - lo
     eng = asm.Engine(local_rank)
-    # everything (kernels, counters, the all-reduce) is ordered on torch's current stream
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    # ONE stream for everything: the library's kernels, torch's ops on the counters and the all-reduce.  torch's default
+    # stream is HIP's legacy stream (handle 0), which the library's own non-blocking stream would never wait for, so the
+    # bench runs inside a real torch stream and hands that to the library.
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        eng.set_stream(stream.cuda_stream)
+        out = run(args, asm, eng, torch, dist, stream, rank, world, cfg, params, first, n, coll_device)
+    if rank == 0:
+        quiet.emit(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run(args, asm, eng, torch, dist, stream, rank, world, cfg, params, first, n, coll_device):
     batch = eng.generate(cfg, first, n)  # this rank's shard of the seeded stream, straight into HBM
     aligners = [asm.NW, asm.LEAP, asm.GREEDY] if args.workload != "C3" else [asm.LEAP, asm.GREEDY]
     d_pen = {a: eng.malloc(4 * n) for a in aligners}
     counters = torch.zeros(4, dtype=torch.int64, device="cuda")  # total, nw_ok, leap_ok, greedy_ok
     d_cnt = counters.data_ptr()
-
     d_nw, d_leap, d_greedy = d_pen.get(asm.NW), d_pen.get(asm.LEAP), d_pen.get(asm.GREEDY)
 
-    def step(timers=None):
+    def step(timers=None, b=batch, repack=True):
         if timers is None:
             # `_run_benchmark` for the whole batch: pack, aligners, counters — one C-ABI call, five launches
-            eng.run_benchmark_async(batch, params, d_nw, d_leap, d_greedy, d_cnt, repack=True)
+            eng.run_benchmark_async(b, params, d_nw, d_leap, d_greedy, d_cnt, repack=repack)
             return
-        seq = [("pack", lambda: eng.pack_async(batch))]
+        seq = [("pack", lambda: eng.pack_async(b))]
         for a in aligners:
             hint = d_nw if a == asm.LEAP else None  # as asm_run_benchmark_async does: LEAP scheduled by the NW penalties
-            seq.append((asm.ALIGNER_NAMES[a], lambda a=a, hint=hint: eng.align_hinted_async(batch, a, params, hint, d_pen[a])))
+            seq.append((asm.ALIGNER_NAMES[a], lambda a=a, hint=hint: eng.align_hinted_async(b, a, params, hint, d_pen[a])))
         for name, fn in seq:
             t = eng.timer()
             t.start()
@@ -175,30 +285,54 @@ def main():
     eng.synchronize()
     kernel_ms = {k: float(np.mean([t.elapsed_ms() for t in v])) for k, v in timers.items()}
     dom = max(kernel_ms, key=kernel_ms.get)
+    if dist is not None:  # warm the collective up outside the timed region (RCCL builds its rings on first use)
+        dist.all_reduce(torch.zeros(4, dtype=torch.int64, device=coll_device))
     barrier()
     counters.zero_()
     # the dominant kernel's duration INSIDE the timed region: HIP events recorded by the library on the stream that kernel
     # is launched on (Greedy: the handle's side stream, beside NW -> LEAP); only this one kernel is bracketed, because an
     # event record keeps the next kernel of its stream from starting early (all four cost ~8 % of the step)
     eng.profile_enable(args.steps, 1 << names.index(dom))
+    ev_ar = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    ar_wall = None
     if dist is not None:
-        dist.all_reduce(counters)  # the only collective: 32 bytes over xGMI
+        if coll_device.type == "cuda":
+            ev_ar[0].record(stream)
+            dist.all_reduce(counters)  # the only collective: 32 bytes over xGMI, ordered after the last step on `stream`
+            ev_ar[1].record(stream)
+        else:  # gloo rehearsal: through the host
+            stream.synchronize()
+            t_ar = time.perf_counter()
+            host = counters.cpu()
+            dist.all_reduce(host)
+            counters.copy_(host)
+            ar_wall = (time.perf_counter() - t_ar) * 1e3
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
+    elapsed = elapsed_local
+    per_rank_ms = [elapsed_local / args.steps * 1e3]
+    allreduce_ms = None
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        allreduce_ms = ar_wall if ar_wall is not None else float(ev_ar[0].elapsed_time(ev_ar[1]))
+        tt = torch.tensor([elapsed_local], dtype=torch.float64, device=coll_device)
+        parts = [torch.empty_like(tt) for _ in range(world)]
+        dist.all_gather(parts, tt)
+        per_rank_ms = [float(p.item()) / args.steps * 1e3 for p in parts]
+        elapsed = max(float(p.item()) for p in parts)
 
     cnt = counters.cpu().numpy().copy()
     region = eng.profile_read(args.steps)
     eng.profile_enable(0, 0)
     q_dom = names.index(dom)
     region_ms = {dom: float(region[:, q_dom].mean())} if region.shape[0] and (region[:, q_dom] >= 0).all() else {dom: kernel_ms[dom]}
+
+    sequential = None
+    if not args.no_sequential and asm.GREEDY in aligners:
+        sequential = sequential_leg(args, asm, eng, torch, dist, rank, world, cfg, params, first, n, d_pen, coll_device, barrier)
 
     coverage = None
     if rank == 0 and asm.NW in aligners and (params.x, params.o, params.e) == (1, 1, 1):
@@ -207,67 +341,115 @@ def main():
         coverage = {"greedy_pct": 100.0 * cov["covered"] / max(n - cov["undetermined"], 1),
                     "undetermined_pairs": cov["undetermined"],
                     "note": "NW traceback tie-break is this library's (parasail's is unpinned); README.md:36 reports 94.213"}
-    if rank == 0:
-        total_pairs = (args.total_pairs if args.total_pairs else world * n) * args.steps
-        value = total_pairs / elapsed
-        hb = batch.download()
-        m_len, n_len = hb.lengths()
-        if dom == "pack":
-            alg_bytes = float((m_len + n_len).sum() + 68 * n)  # ASCII in, planes + lengths out
-        else:
-            alg_bytes = float(algorithmic_bytes(m_len, n_len, 1))
-        achieved = alg_bytes / (region_ms[dom] * 1e-3) / 1e9
-        alone = alg_bytes / (kernel_ms[dom] * 1e-3) / 1e9
-        out = {
-            "metric": "alignments/sec (1e6-pair batch, 100bp, err=0.10) per GPU; NW penalty bit-exact %",
-            "value": value,
-            "unit": "read pairs/s through NW+LEAP+Greedy (whole job)",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "strong" if args.total_pairs else "weak",
-            "vs_baseline": None,
-            "dtype": "u64",
-            "data": "synthetic",
-            "config": {
-                "workload": f"{args.workload}: {n} pairs per GPU, len {cfg.len_lo}-{cfg.len_hi}, err {cfg.err:.2f}, "
-                            f"k={params.k}, x=o=e={params.x},{params.o},{params.e}, aligners "
-                            + "+".join(asm.ALIGNER_NAMES[a] for a in aligners) + ", greedy tails=clean",
-                "pairs_per_gpu": n,
-                "sharding": "independent pairs, contiguous shard per rank, one 32-byte all-reduce of counters",
-            },
-            "kernel_ms_in_timed_region": region_ms,
-            "kernel_ms": kernel_ms,
-            "kernel_pairs_per_s": {k: n / (v * 1e-3) for k, v in kernel_ms.items()},
-            "leap_greedy_pairs_per_s_per_gpu": n / ((kernel_ms.get("leap", 0) + kernel_ms.get("greedy", 0)) * 1e-3),
-            "accuracy_pct": {asm.ALIGNER_NAMES[a]: 100.0 * float(cnt[1 + a]) / float(cnt[0]) for a in aligners}
-            if asm.NW in aligners else None,
-            "coverage_pct": coverage,
-            "roofline": {
-                "bound": "hbm",
-                "kernel": dom,
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": pmc_traffic(dom, n),
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "avg_launch_ms": region_ms[dom],
-                "note": "avg_launch_ms: HIP events on the launching stream inside the timed region, where this kernel shares the "
-                        "GPU with the other chain; `standalone` = the same kernel with the GPU to itself; integer-VALU-bound path "
-                        "(SURVEY.md F7): the binding roofline is in `valu` (stand-alone launch)",
-                "standalone": {"avg_launch_ms": kernel_ms[dom], "achieved": alone, "frac": alone / HBM_PEAK_GBPS},
-                "valu": valu_roofline(dom, n, kernel_ms[dom]),
-            },
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out.update(cpu_baseline_and_parity(asm, eng, hb, batch, params, aligners, args.cpu_sample, d_pen))
-        quiet.emit(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rank != 0:
+        return None
+    # leave the penalties of the CLEAN-mode batch in d_pen for the parity leg below
+    step(repack=False)
+    eng.synchronize()
+    total_pairs = (args.total_pairs if args.total_pairs else world * n) * args.steps
+    value = total_pairs / elapsed
+    hb = batch.download()
+    m_len, n_len = hb.lengths()
+    if dom == "pack":
+        alg_bytes = float((m_len + n_len).sum() + 68 * n)  # ASCII in, planes + lengths out
+    else:
+        alg_bytes = float(algorithmic_bytes(m_len, n_len, 1))
+    achieved = alg_bytes / (region_ms[dom] * 1e-3) / 1e9
+    alone = alg_bytes / (kernel_ms[dom] * 1e-3) / 1e9
+    pmc, pmc_why = load_pmc(args.workload)
+    entry = pmc_for(pmc, dom, n)
+    out = {
+        "metric": "alignments/sec (1e6-pair batch, 100bp, err=0.10) per GPU; NW penalty bit-exact %",
+        "value": value,
+        "unit": "read pairs/s through NW+LEAP+Greedy (whole job)",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong" if args.total_pairs else "weak",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.workload}: {n} pairs per GPU, len {cfg.len_lo}-{cfg.len_hi}, err {cfg.err:.2f}, "
+                        f"k={params.k}, x=o=e={params.x},{params.o},{params.e}, aligners "
+                        + "+".join(asm.ALIGNER_NAMES[a] for a in aligners) + ", greedy tails=clean",
+            "pairs_per_gpu": n,
+            "sharding": "independent pairs, contiguous shard per rank, one 32-byte all-reduce of counters",
+        },
+        "ms_per_step_per_rank": per_rank_ms,
+        "allreduce_ms": allreduce_ms,
+        "kernel_ms_in_timed_region": region_ms,
+        "kernel_ms": kernel_ms,
+        "kernel_pairs_per_s": {k: n / (v * 1e-3) for k, v in kernel_ms.items()},
+        "leap_greedy_pairs_per_s_per_gpu": n / ((kernel_ms.get("leap", 0) + kernel_ms.get("greedy", 0)) * 1e-3),
+        "accuracy_pct": {asm.ALIGNER_NAMES[a]: 100.0 * float(cnt[1 + a]) / float(cnt[0]) for a in aligners}
+        if asm.NW in aligners else None,
+        "counters": {"total": int(cnt[0]), "nw_ok": int(cnt[1]), "leap_ok": int(cnt[2]), "greedy_ok": int(cnt[3]),
+                     "expected_total": (args.total_pairs if args.total_pairs else world * n) * args.steps},
+        "coverage_pct": coverage,
+        "sequential_mode": sequential,
+        "roofline": {
+            "bound": "hbm",
+            "kernel": dom,
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": entry.get("traffic_bytes") if entry else None,
+            "traffic_source": (entry or {}).get("source") or pmc_why,
+            "traffic_kernel": (entry or {}).get("kernel_name"),
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "avg_launch_ms": region_ms[dom],
+            "note": "avg_launch_ms: HIP events on the launching stream inside the timed region, where this kernel shares the "
+                    "GPU with the other chain; `standalone` = the same kernel with the GPU to itself; integer-VALU-bound path "
+                    "(SURVEY.md F7): the binding roofline is in `valu` (stand-alone launch)",
+            "standalone": {"avg_launch_ms": kernel_ms[dom], "achieved": alone, "frac": alone / HBM_PEAK_GBPS},
+            "valu": valu_roofline(entry, pmc, kernel_ms[dom]) if pmc else None,
+        },
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out.update(cpu_baseline_and_parity(asm, eng, hb, batch, params, aligners, args.cpu_sample, d_pen))
+    return out
+
+
+def sequential_leg(args, asm, eng, torch, dist, rank, world, cfg, params, first, n, d_pen, coll_device, barrier):
+    """The reference AS RUN (GASMA/hurdle_matrix.h:625-631): Greedy's conversion of pair t sees the stale bytes earlier pairs
+    left in the two persistent buffers.  A step here = resolve the stale tails of the shard from the state the shards before
+    it leave behind (three device passes over a clean packing, asm_tails.h) + pack with the tails OR-ed in + the aligners +
+    counters.  With N ranks the shards are chained by ONE all-gather of 256-byte summaries (asm.chain_tail_state), so the
+    N-GPU result equals the single-process run over the whole file."""
+    seq = eng.generate(cfg, first, n)
+    summary = eng.tail_summary(seq)
+    state = asm.chain_tail_state(summary, n, dist, coll_device)
+    d_nw, d_leap, d_greedy = d_pen.get(asm.NW), d_pen.get(asm.LEAP), d_pen.get(asm.GREEDY)
+    steps = max(3, min(args.steps, 10))
+    eng.resolve_tails(seq, state)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.resolve_tails(seq, state)  # tails + pack (synchronous)
+        eng.run_benchmark_async(seq, params, d_nw, d_leap, d_greedy, None, repack=False)
+    barrier()
+    dt = time.perf_counter() - t0
+    out = {"ms_per_step": dt / steps * 1e3, "steps": steps, "pairs_per_s_this_rank": n * steps / dt,
+           "what": "tail resolve (3 passes) + pack with tails + aligners, wall clock with a sync per step; "
+                   "N ranks chain their shards through one all-gather of 256-byte summaries"}
+    if rank == 0 and not args.no_cpu_baseline:
+        from tests import oracle_binding
+
+        orc = oracle_binding.load_oracle()
+        s = min(args.cpu_sample, n)
+        sub = seq.download().slice(0, s)
+        got = eng.to_host(d_greedy, n)[:s]
+        want = orc.greedy(sub, params.k, params.x, params.o, params.e, mode=0)
+        clean = orc.greedy(sub, params.k, params.x, params.o, params.e, mode=1)
+        out["greedy_bit_exact_pct_vs_oracle_sequential"] = 100.0 * float((got == want).mean())
+        out["pairs_where_sequential_differs_from_clean_pct"] = 100.0 * float((want != clean).mean())
+        out["sample"] = s
+    seq.free()
+    return out
 
 
 def cpu_baseline_and_parity(asm, eng, hb, batch, params, aligners, sample, d_pen):

@@ -124,6 +124,24 @@ int asm_reference_upload(asm_handle* h, const char* text, size_t len, asm_refere
 int asm_reference_free(asm_handle* h, asm_reference* r);
 int asm_batch_from_hits(asm_handle* h, const asm_reference* ref, int64_t n, const char* reads, const uint32_t* read_off,
                         const uint64_t* hit_pos, int greedy_mode, asm_batch** out);
+/* Greedy's sequential mode ACROSS batches — shards of one file on several GPUs, or chunks of a streamed file.  The
+ * reference's two 128-byte buffers (hurdle_matrix.h:136-137) live on from pair to pair: reset() overwrites their first m / n
+ * bytes (:630-631) and every conversion permutes them in place (bit_convert.cpp:265-330), so what pair t sees beyond its
+ * strings depends on every earlier pair of the file.  Only the 2-bit codes matter, so the chain's state is 256 codes,
+ * state[side*128 + slot], side 0 = read buffer, 1 = reference buffer; a file starts from zeros (NUL bytes).
+ *   asm_batch_tail_summary  — what one batch does to the buffers: summary[side*128 + s] = code of the last character the
+ *                             batch writes on the trajectory that sits in slot s before its first pair, 0xFF = untouched.
+ *                             Works on a batch of either mode; needs no carry-in, so all shards compute it in parallel.
+ *   asm_tail_state_advance  — host only, no device: state after a batch of n_pairs = its summary applied to the state
+ *                             before it (the permutation has order 10: n_pairs mod 10 decides where trajectories end).
+ *   asm_batch_resolve_tails — (re)derives the batch's tails from the given state before its first pair (NULL = zeros),
+ *                             switches the batch to ASM_GREEDY_SEQUENTIAL and repacks it.  Synchronous.
+ * Shard r of a file: summaries of all shards are exchanged (one all-gather of 256 bytes + the shard sizes), every rank folds
+ * the summaries of the shards before its own with asm_tail_state_advance and resolves — the N-GPU result then equals the
+ * reference run over the whole file. */
+int asm_batch_tail_summary(asm_handle* h, const asm_batch* b, uint8_t* summary /* [256] */);
+int asm_tail_state_advance(uint8_t* state /* [256], in/out */, const uint8_t* summary /* [256] */, int64_t n_pairs);
+int asm_batch_resolve_tails(asm_handle* h, asm_batch* b, const uint8_t* state /* [256] or NULL */);
 int asm_batch_free(asm_handle* h, asm_batch* b);
 int64_t asm_batch_size(const asm_batch* b);
 int asm_batch_max_length(const asm_batch* b);

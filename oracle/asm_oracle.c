@@ -131,11 +131,21 @@ static void convert_permute(uint8_t* buf) {
     memcpy(buf, t, 128);
 }
 
+/* Buffer content before the first pair of a sequential-mode batch (default zeros) and after its last pair: lets the tests
+ * run the reference's chain over a file in pieces (shards / chunks) and compare with the run over the whole file. */
+static uint8_t g_init_buffers[256];
+static uint8_t g_final_buffers[256];
+void orc_greedy_set_initial_buffers(const uint8_t* ab /* A[128] then B[128]; NULL = zeros */) {
+    if (ab) memcpy(g_init_buffers, ab, 256);
+    else memset(g_init_buffers, 0, 256);
+}
+void orc_greedy_get_final_buffers(uint8_t* ab) { memcpy(ab, g_final_buffers, 256); }
+
 int orc_greedy_views(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
                      const uint32_t* ref_off, int mode, uint8_t* views) {
-    uint8_t A[128], B[128]; /* hurdle_matrix.h:136-137; initial content pinned to zero */
-    memset(A, 0, 128);
-    memset(B, 0, 128);
+    uint8_t A[128], B[128]; /* hurdle_matrix.h:136-137; initial content pinned (zeros unless a test set it) */
+    memcpy(A, g_init_buffers, 128);
+    memcpy(B, g_init_buffers + 128, 128);
     for (int64_t i = 0; i < n; i++) {
         int m = (int)(read_off[i + 1] - read_off[i]), nn = (int)(ref_off[i + 1] - ref_off[i]);
         if (m > 128) m = 128;
@@ -153,6 +163,8 @@ int orc_greedy_views(int64_t n, const char* reads, const uint32_t* read_off, con
             convert_permute(B);
         }
     }
+    memcpy(g_final_buffers, A, 128);
+    memcpy(g_final_buffers + 128, B, 128);
     return 0;
 }
 

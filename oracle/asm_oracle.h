@@ -51,6 +51,11 @@ int orc_greedy_batch_typed(int64_t n, const char* reads, const uint32_t* read_of
 int orc_greedy_views(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
                      const uint32_t* ref_off, int mode, uint8_t* views);
 
+/* Sequential mode in pieces: content of the A and B buffers before the first pair of the next orc_greedy_* call (NULL = zeros,
+ * the default) and after the last pair of the previous one.  Not thread safe; test use only. */
+void orc_greedy_set_initial_buffers(const uint8_t* ab /* [256] */);
+void orc_greedy_get_final_buffers(uint8_t* ab /* [256] */);
+
 /* LEAP (banded affine Landau-Vishkin "BAG") penalty = final_ED, as benchmarked.
  * Follows GASMA/benchmark/LEAP_SIMD/LV_BAG.cpp:9-23,65-245,356-358 with init(k,200,ED_GLOBAL,x,o,e).
  * eds[i] = -1 when no lane passes within af_threshold=200 (reference returns a stale value there). */

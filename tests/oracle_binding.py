@@ -36,6 +36,29 @@ def _cigars(buf, n, stride):
     return [raw[i * stride:(i + 1) * stride].split(b"\0", 1)[0].decode() for i in range(n)]
 
 
+def base_code(c):
+    """bit_convert.cpp:340-355: A=00 C=01 G=10 T=11, anything else 00."""
+    return {ord("C"): 1, ord("G"): 2, ord("T"): 3}.get(int(c), 0)
+
+
+_PERM_P = (0, 2, 1, 3, 4, 6, 5, 7)
+
+
+def tail_slot_after(slot, n):
+    """Where the byte sitting in `slot` before a pair's conversion sits n pairs later: after[q] = before[8*(q%16) + P[q//16]]
+    (bit_convert.cpp:265-330), so a byte moves from y to the q with SRC[q] = y; the permutation has order 10."""
+    inv = {8 * (q % 16) + _PERM_P[q // 16]: q for q in range(128)}
+    for _ in range(n % 10):
+        slot = inv[slot]
+    return slot
+
+
+def codes_to_buffers(state):
+    """2-bit codes -> bytes the reference's conversion maps to them (0 -> NUL, as a fresh buffer)."""
+    lut = np.array([0, ord("C"), ord("G"), ord("T")], np.uint8)
+    return lut[np.asarray(state, np.uint8)]
+
+
 class Oracle:
     def __init__(self, lib):
         self.lib = lib
@@ -71,6 +94,41 @@ class Oracle:
         if steps:
             out.append(st)
         return out[0] if len(out) == 1 else tuple(out)
+
+    # ---- sequential mode in pieces (shards of a file / chunks of a stream) ----
+    def set_initial_buffers(self, ab=None):
+        """Content of the reference's A and B buffers (uint8[256]) before the next greedy call's first pair; None = zeros."""
+        self.lib.orc_greedy_set_initial_buffers.argtypes = [_vp]
+        if ab is None:
+            self.lib.orc_greedy_set_initial_buffers(None)
+        else:
+            buf = np.ascontiguousarray(ab, np.uint8)
+            assert buf.size == 256
+            self.lib.orc_greedy_set_initial_buffers(buf.ctypes.data)
+
+    def final_buffers(self):
+        self.lib.orc_greedy_get_final_buffers.argtypes = [_vp]
+        out = np.zeros(256, np.uint8)
+        self.lib.orc_greedy_get_final_buffers(out.ctypes.data)
+        return out
+
+    def tail_summary(self, hb):
+        """What the batch does to the buffers, in the product's terms (asm_batch_tail_summary): summary[side*128 + s] = code of
+        the last character written on the trajectory that starts in slot s, 0xFF when the batch never writes on it.  Found by
+        running the buffer model from sentinel bytes and seeing which survive."""
+        self.set_initial_buffers(np.full(256, 0xEE, np.uint8))
+        try:
+            self.greedy_views(hb, 0)
+            fin = self.final_buffers()
+        finally:
+            self.set_initial_buffers(None)
+        out = np.full(256, 0xFF, np.uint8)
+        for side in range(2):
+            for s in range(128):
+                c = fin[side * 128 + tail_slot_after(s, hb.n)]
+                if c != 0xEE:
+                    out[side * 128 + s] = base_code(c)
+        return out
 
     def greedy_views(self, hb, mode):
         keep, args = _batch_args(hb)

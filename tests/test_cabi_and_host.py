@@ -117,3 +117,26 @@ def test_shard_bounds_cover_batch(asm):
         spans = [asm.shard_bounds(total, world, r) for r in range(world)]
         assert spans[0][0] == 0 and spans[-1][1] == total
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def test_tail_state_advance_is_the_reference_buffer_model(asm, oracle):
+    """asm_tail_state_advance (host function of the product, no GPU) against the oracle's model of the reference's two
+    persistent buffers (hurdle_matrix.h:136-137,630-631; bit_convert.cpp:265-330): folding per-chunk summaries reproduces the
+    buffer content after every chunk, for chunk sizes with every phase mod 10, empty chunks included."""
+    from tests import oracle_binding as ob
+
+    cfg, _, _ = asm.workload("C5")
+    sizes = [1, 9, 10, 0, 11, 137, 2560, 3, 255, 64]
+    state = np.zeros(256, np.uint8)
+    first = 0
+    oracle.set_initial_buffers(None)
+    whole = asm.generate_pairs(cfg, 0, sum(sizes))
+    for n in sizes:
+        hb = asm.generate_pairs(cfg, first, n)
+        state = asm.tail_state_advance(state, oracle.tail_summary(hb), n)
+        first += n
+        oracle.greedy_views(whole.slice(0, first), 0)          # the reference's chain over the file so far
+        want = np.array([ob.base_code(c) for c in oracle.final_buffers()], np.uint8)
+        assert np.array_equal(state, want), f"after {first} pairs"
+    with pytest.raises(asm.AsmError):
+        asm.tail_state_advance(state, np.full(256, 7, np.uint8), 5)

@@ -1,0 +1,70 @@
+"""bench.py's own launch paths on the one-GPU box: the self-started ranks (two gloo ranks sharing the card: the N>1 code path,
+not a scaling measurement), the RCCL collective with a single rank, and the refusal to run N ranks on fewer GPUs.  The
+counters of the timed region are checked against the oracle: with everything on ONE stream they are exact, not racy."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(extra_env, *argv, expect_ok=True):
+    env = dict(os.environ, **extra_env)
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=900)
+    if not expect_ok:
+        return r
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]          # the contract: ONE JSON line on stdout
+    return json.loads(lines[0])
+
+
+def _expected_counts(asm, oracle, first, n):
+    cfg, _, params = asm.workload("C2")
+    hb = asm.generate_pairs(cfg, first, n)
+    nw, leap, greedy = oracle.nw(hb), oracle.leap(hb, params.k), oracle.greedy(hb, params.k, mode=1)
+    return np.array([n, n, int((leap == nw).sum()), int((greedy == nw).sum())])
+
+
+def test_self_started_ranks_share_one_stream_with_the_collective(asm, oracle):
+    n, steps = 20000, 3
+    out = _bench({"ASM_DIST_BACKEND": "gloo"}, "--gpus", "2", "--pairs", str(n), "--steps", str(steps), "--warmup", "1",
+                 "--cpu-sample", "20000", "--no-cpu-baseline")
+    assert out["n_gpus"] == 2 and len(out["ms_per_step_per_rank"]) == 2 and out["allreduce_ms"] is not None
+    want = steps * (_expected_counts(asm, oracle, 0, n) + _expected_counts(asm, oracle, n, n))   # rank r owns [r*n, (r+1)*n)
+    c = out["counters"]
+    assert [c["total"], c["nw_ok"], c["leap_ok"], c["greedy_ok"]] == want.tolist()
+    assert c["total"] == c["expected_total"]
+    assert out["sequential_mode"]["ms_per_step"] > 0
+
+
+def test_single_rank_through_rccl_and_sequential_leg(asm, oracle):
+    n, steps = 30000, 4
+    out = _bench({"ASM_FORCE_DIST": "1"}, "--pairs", str(n), "--steps", str(steps), "--warmup", "1", "--cpu-sample", "30000")
+    want = steps * _expected_counts(asm, oracle, 0, n)
+    c = out["counters"]
+    assert [c["total"], c["nw_ok"], c["leap_ok"], c["greedy_ok"]] == want.tolist()
+    assert out["bit_exact_pct_vs_oracle"]["greedy"] == 100.0 and out["bit_exact_pct_vs_oracle"]["nw"] == 100.0
+    seq = out["sequential_mode"]
+    assert seq["greedy_bit_exact_pct_vs_oracle_sequential"] == 100.0
+    assert seq["pairs_where_sequential_differs_from_clean_pct"] > 0       # the two modes really differ on this input
+    assert out["roofline"]["frac"] > 0 and out["cpu_baseline"]["value"] > 0
+
+
+def test_more_ranks_than_gpus_is_refused(asm):
+    have = asm.device_count()
+    r = _bench({}, "--gpus", str(have + 1), "--pairs", "1000", "--steps", "1", expect_ok=False)
+    assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)
+    # a launcher that started a different number of ranks than --gpus says
+    r = _bench({}, "--gpus", "1", "--pairs", "1000", "--steps", "1", expect_ok=False)
+    assert r.returncode == 0
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--pairs", "1000", "--steps", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr

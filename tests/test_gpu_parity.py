@@ -3,7 +3,7 @@ Bar: bit-exact int32 penalties.  Sizes are what the oracle finishes in seconds."
 import numpy as np
 import pytest
 
-from tests.util import KNOWN_PAIRS, random_ragged_batch
+from tests.util import KNOWN_PAIRS, greedy_defined, random_ragged_batch
 
 pytestmark = pytest.mark.gpu
 
@@ -55,6 +55,45 @@ def test_sequential_mode_ragged_lengths(asm, engine, oracle):
     want = oracle.greedy(hb, k=3, mode=0)
     got = engine.align(engine.upload(hb, asm.GREEDY_SEQUENTIAL), asm.GREEDY, asm.Params.default(k=3))
     _check("ragged-seq", got, want, hb)
+
+
+@pytest.mark.parametrize("sizes", [(7001, 5000, 2999), (2560, 2560, 10), (13, 0, 9000, 1), (25000,)])
+def test_sequential_mode_chains_across_batches(asm, engine, oracle, sizes):
+    """One file cut into shards / chunks (sizes with every phase mod 10, an empty one, one spanning several 2560-pair chunks):
+    summary per shard on the device -> fold on the host -> resolve each shard from the folded state.  Equals the reference as
+    run over the WHOLE file (oracle mode 0, and the compiled reference where it travelled), which shards that each start from
+    empty buffers do not."""
+    from tests import oracle_binding as ob
+
+    long_cfg = asm.GenConfig.exact(31, 100, 0.10, length_hi=128)
+    mixed_cfg = asm.GenConfig.exact(32, 30, 0.10, length_hi=128)
+    total = sum(sizes)
+    a, b = asm.generate_pairs(long_cfg, 0, total // 3), asm.generate_pairs(mixed_cfg, 0, total - total // 3)
+    hb = asm.HostBatch(np.concatenate([a.reads, b.reads]), np.concatenate([a.read_off, b.read_off[1:] + a.read_off[-1]]),
+                       np.concatenate([a.refs, b.refs]), np.concatenate([a.ref_off, b.ref_off[1:] + a.ref_off[-1]]))
+    params = asm.Params.default(k=3)
+    want, want_cigars = oracle.greedy(hb, k=3, mode=0, cigars=True)
+    if ob.have_reference():
+        ok = greedy_defined(hb, 3)
+        assert np.array_equal(ob.load_reference().greedy(hb, k=3, mode=0)[ok], want[ok])
+    state = np.zeros(256, np.uint8)
+    lo = 0
+    got, got_cigars = [], []
+    for n in sizes:
+        part = hb.slice(lo, lo + n)
+        batch = engine.upload(part, asm.GREEDY_CLEAN)       # uploaded without any knowledge of the pairs before it
+        summary = engine.tail_summary(batch)
+        assert np.array_equal(summary, oracle.tail_summary(part)), f"summary of [{lo}, {lo + n})"
+        engine.resolve_tails(batch, state)
+        cost, cigars, _ = engine.greedy_with_cigar(batch, params, cap=64)
+        got.append(cost)
+        got_cigars += cigars
+        state = asm.tail_state_advance(state, summary, n)
+        lo += n
+    _check("chained", np.concatenate(got), want, hb)
+    assert got_cigars == want_cigars
+    oracle.greedy_views(hb, 0)
+    assert np.array_equal(state, np.array([ob.base_code(c) for c in oracle.final_buffers()], np.uint8))
 
 
 def test_c3_wide_band_150bp(asm, engine, oracle):
