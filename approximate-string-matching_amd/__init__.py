@@ -19,7 +19,7 @@ from typing import Iterable, Optional, Sequence, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libasm_mi355x.so")
+LIB_PATH = os.environ.get("ASM_MI355X_LIB") or os.path.join(_HERE, "libasm_mi355x.so")  # override: A/B builds of the same ABI
 HEADER_PATH = os.path.join(_HERE, "..", "include", "asm_mi355x.h")
 
 NW, LEAP, GREEDY = 0, 1, 2

@@ -15,6 +15,7 @@
 #include "asm_kernels.h"
 #include "asm_wide.h"
 #include "asm_wave.h"
+#include "asm_group.h"
 #include "asm_cover.h"
 #include "asm_tails.h"
 #include "asm_filter.h"
@@ -34,6 +35,9 @@ struct asm_handle {
     bool leap_hint = true;                /* LEAP scheduled by a work hint when one is given (ASM_LEAP_HINT=0 disables) */
     bool bucketing = true;                /* group mixed-length batches by width class (ASM_BUCKET=0 disables) */
     bool wave_kernels = true;             /* wave-per-pair kernels for 6 <= k <= 31 (ASM_WAVE=0: workgroup-per-pair LDS kernels) */
+    bool persist_wide = true;             /* Greedy, k = 6..14: still one thread per pair — up to 29 lane vectors in 512 VGPR+AGPR, one
+                                             wave per SIMD (ASM_PERSIST_WIDE=0: wave per pair) */
+    bool group_kernels = true;            /* Greedy, 32 <= k <= 39: sixteen threads per pair (ASM_GROUP=0: two wavefronts per pair) */
     bool nw_banded = true;                /* banded bit-parallel NW with in-kernel full-height recompute (ASM_NW_BANDED=0) */
     bool leap_band = true;                /* LEAP, wide band: thread per pair with the band in LDS (ASM_LEAP_BAND=0: wave per pair) */
     bool nw_wfa = true;                   /* affine NW: banded wavefront first, full matrix for the rest (ASM_NW_WFA=0: full matrix only) */
@@ -69,6 +73,9 @@ struct asm_batch {
     uint32_t* d_order = nullptr; /* bucketed slot -> pair index (null: identity) */
     uint32_t* d_pos = nullptr;   /* pair index -> bucketed slot (null: identity) */
     uint4* d_tails = nullptr;    /* sequential mode: stale-tail planes, uint4[4][n] in input order */
+    uint4* d_tail_g0 = nullptr;  /* tail resolver scratch (asm_tails.h), allocated on first use: clean granule 0 in input order, */
+    uint32_t* d_tail_l0 = nullptr; /* its lengths, */
+    uint8_t* d_tail_chunks = nullptr; /* per-chunk last writes and carries + the 256-byte summary */
     int nb = 1;
     asm_bucket bk[4];
     PackBuckets pb;
@@ -120,9 +127,12 @@ static hipError_t launch_greedy(asm_handle* h, const asm_bucket& b, const Greedy
     if (h->persist)
         return launch_persistent(h, greedy_persist_kernel<K, false>, b.n, (const uint4*)b.planes, (const uint32_t*)b.lens,
                                  (long)b.n, b.w4, ga, out, cig, h->refill_greedy);
-    hipLaunchKernelGGL(greedy_kernel<K>, dim3(grid_for(b.n)), dim3(ASM_BLOCK), 0, h->stream, b.planes, b.lens, (long)b.n,
-                       b.w4, ga, out, cig);
-    return hipGetLastError();
+    if constexpr (K <= 5) { /* the one-pair-per-thread A/B form (ASM_PERSIST=0) exists for the narrow bands only */
+        hipLaunchKernelGGL(greedy_kernel<K>, dim3(grid_for(b.n)), dim3(ASM_BLOCK), 0, h->stream, b.planes, b.lens, (long)b.n,
+                           b.w4, ga, out, cig);
+        return hipGetLastError();
+    }
+    return hipErrorInvalidValue;
 }
 
 template <int K, int W64>
@@ -296,6 +306,8 @@ int asm_create(asm_handle** out, int device) {
     if ((env = getenv("ASM_LEAP_HINT"))) h->leap_hint = env[0] != '0';
     if ((env = getenv("ASM_BUCKET"))) h->bucketing = env[0] != '0';
     if ((env = getenv("ASM_WAVE"))) h->wave_kernels = env[0] != '0';
+    if ((env = getenv("ASM_GROUP"))) h->group_kernels = env[0] != '0';
+    if ((env = getenv("ASM_PERSIST_WIDE"))) h->persist_wide = env[0] != '0';
     if ((env = getenv("ASM_NW_BANDED"))) h->nw_banded = env[0] != '0';
     if ((env = getenv("ASM_NW_WFA"))) h->nw_wfa = env[0] != '0';
     if ((env = getenv("ASM_LEAP_BAND"))) h->leap_band = env[0] != '0';
@@ -406,6 +418,9 @@ static void batch_release(asm_batch* b) {
     (void)hipFree(b->d_order);
     (void)hipFree(b->d_pos);
     (void)hipFree(b->d_tails);
+    (void)hipFree(b->d_tail_g0);
+    (void)hipFree(b->d_tail_l0);
+    (void)hipFree(b->d_tail_chunks);
     delete b;
 }
 
@@ -453,44 +468,35 @@ static int batch_resolve_tails(asm_handle* h, asm_batch* b, const uint8_t* init2
     if (summary256) memset(summary256, TAIL_NONE, 256);
     if (b->n == 0) return ASM_OK;
     const long nchunks = (b->n + TAIL_CHUNK - 1) / TAIL_CHUNK;
-    uint8_t *d_last = nullptr, *d_carry = nullptr, *d_state = nullptr;
-    uint4* d_g0 = nullptr;
-    uint32_t* d_l0 = nullptr;
-    int rc = ASM_OK;
-    do {
-#define TRY(call)                                                        \
-    if ((call) != hipSuccess) {                                          \
-        rc = fail(h, ASM_ENODEVICE, std::string(#call) + " failed");     \
-        break;                                                           \
+    TailState init;
+    if (init256) memcpy(init.code, init256, 256);
+    else memset(init.code, 0, 256);
+    /* scratch lives with the batch: a streamed file re-resolves every chunk, a bench step every iteration */
+    if (emit && !b->d_tails) HIPCHK(h, hipMalloc((void**)&b->d_tails, sizeof(uint4) * 4 * (size_t)b->n));
+    if (!b->d_tail_g0) {
+        HIPCHK(h, hipMalloc((void**)&b->d_tail_g0, sizeof(uint4) * 4 * (size_t)b->n));
+        HIPCHK(h, hipMalloc((void**)&b->d_tail_l0, sizeof(uint32_t) * (size_t)b->n));
+        HIPCHK(h, hipMalloc((void**)&b->d_tail_chunks, (size_t)nchunks * 512 + 256)); /* last[nchunks][256], carry[nchunks][256], summary[256] */
     }
-        if (emit && !b->d_tails) TRY(hipMalloc((void**)&b->d_tails, sizeof(uint4) * 4 * (size_t)b->n));
-        TRY(hipMalloc((void**)&d_g0, sizeof(uint4) * 4 * (size_t)b->n));
-        TRY(hipMalloc((void**)&d_l0, sizeof(uint32_t) * (size_t)b->n));
-        TRY(hipMalloc((void**)&d_last, (size_t)nchunks * 256));
-        TRY(hipMalloc((void**)&d_carry, (size_t)nchunks * 256));
-        TRY(hipMalloc((void**)&d_state, 512)); /* [0,256) init, [256,512) summary */
-        if (init256) TRY(hipMemcpyAsync(d_state, init256, 256, hipMemcpyHostToDevice, h->stream));
-        PackBuckets one{};
-        one.nb = 1, one.w4[0] = 1, one.start[0] = 0, one.start[1] = b->n, one.plane_off[0] = 0;
-        TRY(launch_pack(h, b, nullptr, d_g0, d_l0, one, nullptr));
-        hipLaunchKernelGGL(tails_chunk_kernel, dim3((unsigned)nchunks), dim3(256), 0, h->stream, d_g0, d_l0, (long)b->n, 1,
-                           d_last);
-        hipLaunchKernelGGL(tails_carry_kernel, dim3(1), dim3(256), 0, h->stream, d_last, d_carry, nchunks,
-                           (const uint8_t*)(init256 ? d_state : nullptr), summary256 ? d_state + 256 : (uint8_t*)nullptr);
-        if (emit)
-            hipLaunchKernelGGL(tails_emit_kernel, dim3((unsigned)nchunks), dim3(256), 0, h->stream, d_g0, d_l0, (long)b->n, 1,
-                               d_carry, b->d_tails);
-        TRY(hipGetLastError());
-        if (summary256) TRY(hipMemcpyAsync(summary256, d_state + 256, 256, hipMemcpyDeviceToHost, h->stream));
-        TRY(hipStreamSynchronize(h->stream));
-#undef TRY
-    } while (0);
-    (void)hipFree(d_last);
-    (void)hipFree(d_carry);
-    (void)hipFree(d_state);
-    (void)hipFree(d_g0);
-    (void)hipFree(d_l0);
-    return rc;
+    uint8_t* const d_last = b->d_tail_chunks;
+    uint8_t* const d_carry = d_last + (size_t)nchunks * 256;
+    uint8_t* const d_sum = d_carry + (size_t)nchunks * 256;
+    PackBuckets one{};
+    one.nb = 1, one.w4[0] = 1, one.start[0] = 0, one.start[1] = b->n, one.plane_off[0] = 0;
+    HIPCHK(h, launch_pack(h, b, nullptr, b->d_tail_g0, b->d_tail_l0, one, nullptr));
+    hipLaunchKernelGGL(tails_chunk_kernel, dim3((unsigned)nchunks), dim3(256), 0, h->stream, b->d_tail_g0, b->d_tail_l0, (long)b->n,
+                       1, d_last);
+    hipLaunchKernelGGL(tails_carry_kernel, dim3(1), dim3(256), 0, h->stream, d_last, d_carry, nchunks, init,
+                       summary256 ? d_sum : (uint8_t*)nullptr);
+    if (emit)
+        hipLaunchKernelGGL(tails_emit_kernel, dim3((unsigned)nchunks), dim3(256), 0, h->stream, b->d_tail_g0, b->d_tail_l0,
+                           (long)b->n, 1, d_carry, b->d_tails);
+    HIPCHK(h, hipGetLastError());
+    if (summary256) {
+        HIPCHK(h, hipMemcpyAsync(summary256, d_sum, 256, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return ASM_OK;
 }
 
 /* Common tail of upload/generate once ASCII + offsets are resident and b->maxlen is known: group the pairs into width
@@ -849,7 +855,6 @@ int asm_batch_resolve_tails(asm_handle* h, asm_batch* b, const uint8_t* state) {
     b->greedy_mode = ASM_GREEDY_SEQUENTIAL;
     int rc = batch_resolve_tails(h, b, state, nullptr, true);
     if (!rc) rc = asm_batch_pack_async(h, b);
-    if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(h, ASM_ENODEVICE, "asm_batch_resolve_tails: stream synchronize failed");
     return rc;
 }
 
@@ -930,8 +935,17 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
             case 3: HIPCHK(h, launch_greedy<3>(h, b, ga, out, cig)); break;
             case 4: HIPCHK(h, launch_greedy<4>(h, b, ga, out, cig)); break;
             case 5: HIPCHK(h, launch_greedy<5>(h, b, ga, out, cig)); break;
+#define GREEDY_WIDE_CASE(KK) \
+            case KK: if (h->persist_wide && h->persist && p->k == KK) { HIPCHK(h, launch_greedy<KK>(h, b, ga, out, cig)); break; } /* else: falls through to the kernels below */
+            GREEDY_WIDE_CASE(6) GREEDY_WIDE_CASE(7) GREEDY_WIDE_CASE(8) GREEDY_WIDE_CASE(9) GREEDY_WIDE_CASE(10) GREEDY_WIDE_CASE(11)
+            GREEDY_WIDE_CASE(12) GREEDY_WIDE_CASE(13) GREEDY_WIDE_CASE(14)
+#undef GREEDY_WIDE_CASE
             default:
-                if (p->k <= ASM_WAVE_MAX_K && h->wave_kernels && unit && !ga.semi)
+                if (h->group_kernels && p->k >= 32 && p->k <= 39 && (long)p->o + 110L * p->e < 16000L) {
+                    /* 65..79 band lanes: sixteen threads per pair, five lanes each (asm_group.h): 1.78 ms per 10^6 C2 pairs
+                     * against 2.25 ms for the two-wavefront kernel */
+                    HIPCHK(h, launch_greedy_group(h->stream, planes, lens, b.n, b.w4, (int)p->k, ga, out, cig, h->num_cus));
+                } else if (p->k <= ASM_WAVE_MAX_K && h->wave_kernels && unit && !ga.semi)
                     launch_wave_per_pair(h->stream, greedy_wave_kernel<true>, b.n, h->num_cus, planes, lens, (long)b.n, b.w4,
                                          (int)p->k, ga, out, cig);
                 else if (p->k <= ASM_WAVE_MAX_K && h->wave_kernels && (long)p->o + 62L * p->e < 16000L)

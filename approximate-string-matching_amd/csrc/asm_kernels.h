@@ -452,9 +452,14 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_persist_kernel(const uint4* 
                                                                    GreedyArgs args, OutMap out,
                                                                    CigarSink cig, int refill_min) {
     constexpr int NL = 2 * K + 1;
+#ifndef ASM_PERSIST_KEEP_LF
+#define ASM_PERSIST_KEEP_LF 5 /* largest K whose flipped lane vectors stay in registers; above it they are rebuilt per look-up */
+#endif
+    constexpr bool KEEP_LF = K <= ASM_PERSIST_KEEP_LF;
+    constexpr int NLF = KEEP_LF ? NL : 1;
     const int x = UNIT ? 1 : args.x, o = UNIT ? 1 : args.o, e = UNIT ? 1 : args.e;
     const bool semi = UNIT ? false : args.semi != 0; /* the UNIT instantiation is GLOBAL only */
-    V128 lo_[NL], lf_[NL];
+    V128 lo_[NL], lf_[NLF];
     int sp[NL], len[NL], nsw[NL], dst[NL], sw[NL], nh[NL];
     V128 dest_vec = v_make(0, 0);
     int m = 0, nn = 0, dest_lane = 0, cur_lane = 0, cur_col = 0, cost = 0, guard = 0, ncig = 0;
@@ -464,7 +469,8 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_persist_kernel(const uint4* 
     wq.init(n);
 #pragma unroll
     for (int j = 0; j < NL; j++) {
-        lo_[j] = lf_[j] = v_make(0, 0);
+        lo_[j] = v_make(0, 0);
+        if (KEEP_LF) lf_[j] = v_make(0, 0);
         sp[j] = -1, len[j] = 0, nsw[j] = 128, dst[j] = 0, sw[j] = nh[j] = 0;
     }
     for (;;) {
@@ -506,7 +512,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_persist_kernel(const uint4* 
                 for (int j = 0; j < NL; j++) {
                     const int lane = j - K;
                     lo_[j] = greedy_lane_vector(A0, A1, B0, B1, lane);
-                    lf_[j] = v_flip_short_hurdles1(lo_[j]);
+                    if (KEEP_LF) lf_[j] = v_flip_short_hurdles1(lo_[j]);
                     sp[j] = -1; /* hurdle_matrix.h:106-119 */
                     len[j] = 0;
                     nsw[j] = 128;
@@ -530,7 +536,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_persist_kernel(const uint4* 
                     int d = lane - cur_lane;
                     nsw[j] = d < 0 ? -d : d;
                     int fz, nx;
-                    v_highway_from(lf_[j], start_col, fz, nx);
+                    v_highway_from(KEEP_LF ? lf_[j] : v_flip_short_hurdles1(lo_[j]), start_col, fz, nx);
                     sp[j] = start_col + fz;
                     len[j] = nx;
                     if (start_col + fz + nx > dst[j]) {

@@ -99,14 +99,17 @@ __global__ __launch_bounds__(256) void tails_chunk_kernel(const uint4* __restric
     chunk_last[(long)blockIdx.x * 256 + threadIdx.x] = (uint8_t)code;
 }
 
-// `init` (optional, [256] = [side][slot]): the codes the two buffers hold before the first pair of this batch — zeros (NUL
+// `init` ([256] = [side][slot]): the codes the two buffers hold before the first pair of this batch — zeros (NUL
 // bytes) for a batch that starts a file, the state after the previous shard/chunk otherwise (asm_tail_state_advance).
 // `summary` (optional, [256]): per trajectory, indexed by its slot before the first pair, the code of the last character the
 // batch wrote on it, or TAIL_NONE when the batch never touched it — the batch's whole effect on the buffers.
+struct TailState { /* passed by value: no host buffer has to outlive the enqueue */
+    uint8_t code[256];
+};
 __global__ __launch_bounds__(256) void tails_carry_kernel(const uint8_t* __restrict__ chunk_last,
                                                           uint8_t* __restrict__ carry_in, long nchunks,
-                                                          const uint8_t* __restrict__ init, uint8_t* __restrict__ summary) {
-    uint32_t cur = init ? (uint32_t)init[threadIdx.x] : 0u; /* a file starts with NUL bytes: code 00 */
+                                                          TailState init, uint8_t* __restrict__ summary) {
+    uint32_t cur = (uint32_t)init.code[threadIdx.x]; /* a file starts with NUL bytes: code 00 */
     uint32_t last = TAIL_NONE;
     for (long c = 0; c < nchunks; c++) {
         const uint32_t s = chunk_last[c * 256 + threadIdx.x];

@@ -434,27 +434,34 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_wave_kernel(const uint4* __r
             const int best_cost = lane_read(sw + hc, bt);
             if (best_len <= 0) break; /* hurdle_matrix.h:358-361 — uniform */
             // ---- _choose_best_highway ----
-            const V128 best_vec = v_make(
-                (u64)(unsigned)lane_read((int)(unsigned)lo_.lo, bt) | ((u64)(unsigned)lane_read((int)(lo_.lo >> 32), bt) << 32),
-                (u64)(unsigned)lane_read((int)(unsigned)lo_.hi, bt) | ((u64)(unsigned)lane_read((int)(lo_.hi >> 32), bt) << 32));
-            const int best_from_sp = v_ones_from(best_vec, best_sp);
-            int inter = 0x3fffffff, total = 0x3fffffff;
-            if (active && lane != best && !(sp + fwd_col(lane, best) > best_sp)) {
-                const int endp = sp + len;
-                inter = sw + nh;
-                const int tail = x * v_pop_between_pre(best_vec, fwd_col(lane, best) + endp, best_sp, best_from_sp);
-                total = inter + lane_penalty(lane, best, o, e) + (tail > 0 ? tail : 0);
-            }
-            // The reference folds lanes in ascending order, accepting a lane only if it is no worse than the last
-            // accepted one in both total and intermediate cost.  Thresholds only ever go down from best_cost, so lanes
-            // above it can be dropped up front; the few that remain are folded in lane order with scalar code.
-            unsigned long long cmask = __ballot(total <= best_cost && inter <= best_cost);
-            int small_total = best_cost, small_inter = best_cost, ct = bt;
-            while (cmask) {
-                const int j = __builtin_ctzll(cmask);
-                cmask &= cmask - 1ull;
-                const int tj = lane_read(total, j), ij = lane_read(inter, j);
-                if (tj <= small_total && ij <= small_inter) small_total = tj, small_inter = ij, ct = j;
+            // A lane can only be accepted with inter = sw + nh <= best_cost, and sw = lane_penalty(cur_lane, lane) > 0 for every
+            // lane but cur_lane.  With best_cost == 0 that leaves cur_lane, and best_cost == 0 means the best lane has sw == 0,
+            // i.e. it IS cur_lane — which the fold skips.  So the whole search is void then (wave-uniform: a scalar branch).
+            // (Needs sw > 0 off cur_lane: not with a free gap-open, and not in SEMI_GLOBAL's first step.)
+            int ct = bt;
+            if (best_cost > 0 || o <= 0 || (semi && guard == 0)) {
+                const V128 best_vec = v_make(
+                    (u64)(unsigned)lane_read((int)(unsigned)lo_.lo, bt) | ((u64)(unsigned)lane_read((int)(lo_.lo >> 32), bt) << 32),
+                    (u64)(unsigned)lane_read((int)(unsigned)lo_.hi, bt) | ((u64)(unsigned)lane_read((int)(lo_.hi >> 32), bt) << 32));
+                const int best_from_sp = v_ones_from(best_vec, best_sp);
+                int inter = 0x3fffffff, total = 0x3fffffff;
+                if (active && lane != best && !(sp + fwd_col(lane, best) > best_sp)) {
+                    const int endp = sp + len;
+                    inter = sw + nh;
+                    const int tail = x * v_pop_between_pre(best_vec, fwd_col(lane, best) + endp, best_sp, best_from_sp);
+                    total = inter + lane_penalty(lane, best, o, e) + (tail > 0 ? tail : 0);
+                }
+                // The reference folds lanes in ascending order, accepting a lane only if it is no worse than the last
+                // accepted one in both total and intermediate cost.  Thresholds only ever go down from best_cost, so lanes
+                // above it can be dropped up front; the few that remain are folded in lane order with scalar code.
+                unsigned long long cmask = __ballot(total <= best_cost && inter <= best_cost);
+                int small_total = best_cost, small_inter = best_cost;
+                while (cmask) {
+                    const int j = __builtin_ctzll(cmask);
+                    cmask &= cmask - 1ull;
+                    const int tj = lane_read(total, j), ij = lane_read(inter, j);
+                    if (tj <= small_total && ij <= small_inter) small_total = tj, small_inter = ij, ct = j;
+                }
             }
             // ---- _step commit (hurdle_matrix.h:411-433) ----
             cost += lane_read(sw + hc, ct);

@@ -217,6 +217,9 @@ def main():
     if world > 1 or os.environ.get("ASM_FORCE_DIST") == "1":  # ASM_FORCE_DIST=1: exercise the collective path with one rank
         import torch.distributed as dist
 
+        if world == 1:  # ASM_FORCE_DIST=1 without a launcher: a one-rank group on a free local port
+            os.environ.setdefault("RANK", "0"), os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"), os.environ.setdefault("MASTER_PORT", str(free_port()))
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -429,12 +432,12 @@ def sequential_leg(args, asm, eng, torch, dist, rank, world, cfg, params, first,
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        eng.resolve_tails(seq, state)  # tails + pack (synchronous)
+        eng.resolve_tails(seq, state)  # three tail passes over a clean granule-0 packing + pack with the tails OR-ed in
         eng.run_benchmark_async(seq, params, d_nw, d_leap, d_greedy, None, repack=False)
     barrier()
     dt = time.perf_counter() - t0
     out = {"ms_per_step": dt / steps * 1e3, "steps": steps, "pairs_per_s_this_rank": n * steps / dt,
-           "what": "tail resolve (3 passes) + pack with tails + aligners, wall clock with a sync per step; "
+           "what": "tail resolve (clean granule-0 pack + 3 passes) + pack with tails + aligners, all enqueued, wall clock; "
                    "N ranks chain their shards through one all-gather of 256-byte summaries"}
     if rank == 0 and not args.no_cpu_baseline:
         from tests import oracle_binding

@@ -135,7 +135,8 @@ int asm_batch_from_hits(asm_handle* h, const asm_reference* ref, int64_t n, cons
  *   asm_tail_state_advance  — host only, no device: state after a batch of n_pairs = its summary applied to the state
  *                             before it (the permutation has order 10: n_pairs mod 10 decides where trajectories end).
  *   asm_batch_resolve_tails — (re)derives the batch's tails from the given state before its first pair (NULL = zeros),
- *                             switches the batch to ASM_GREEDY_SEQUENTIAL and repacks it.  Synchronous.
+ *                             switches the batch to ASM_GREEDY_SEQUENTIAL and repacks it.  Enqueue only (the state is
+ *                             copied at the call).
  * Shard r of a file: summaries of all shards are exchanged (one all-gather of 256 bytes + the shard sizes), every rank folds
  * the summaries of the shards before its own with asm_tail_state_advance and resolves — the N-GPU result then equals the
  * reference run over the whole file. */

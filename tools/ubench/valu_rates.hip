@@ -14,27 +14,38 @@
 #include <cstdio>
 #include <string>
 #include <vector>
-#define ITER 8192
+#define ITER 32768
 #define CH 16
 
 struct Stamp {
-    unsigned long long cyc, real;
+    unsigned long long cyc, real, r0, r1;
 };
 
-#define STAMP_BEGIN                                                  \
-    const unsigned long long c0 = __builtin_amdgcn_s_memtime();      \
+// All waves of the grid start their loops together: every block checks in on a counter and spins (bounded: 3 ms of the
+// 100 MHz clock, then it goes ahead anyway and the row is reported as not synchronised) until the whole grid has arrived, so
+// the stamped loops of a SIMD's resident waves really run side by side.
+#define STAMP_BEGIN                                                                                              \
+    if (threadIdx.x == 0) {                                                                                      \
+        __hip_atomic_fetch_add(gate, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                            \
+        const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();                                        \
+        while (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x &&                \
+               __builtin_amdgcn_s_memrealtime() - t_in < 300000ull)                                              \
+            __builtin_amdgcn_s_sleep(8);                                                                         \
+    }                                                                                                            \
+    __syncthreads();                                                                                             \
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();                                                  \
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
 #define STAMP_END                                                                                  \
     const unsigned long long c1 = __builtin_amdgcn_s_memtime();                                    \
     const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();                                \
     if ((threadIdx.x & 63) == 0) {                                                                 \
         Stamp s;                                                                                   \
-        s.cyc = c1 - c0, s.real = r1 - r0;                                                         \
+        s.cyc = c1 - c0, s.real = r1 - r0, s.r0 = r0, s.r1 = r1;                                   \
         stamps[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = s;                                  \
     }
 
 #define BENCH32(name, ASM)                                                                                   \
-    __global__ __launch_bounds__(256) void name(uint32_t* out, Stamp* stamps, uint32_t a, uint32_t b) {      \
+    __global__ __launch_bounds__(256) void name(uint32_t* out, Stamp* stamps, unsigned* gate, uint32_t a, uint32_t b) { \
         uint32_t v[CH];                                                                                      \
         for (int c = 0; c < CH; c++) v[c] = a + threadIdx.x * 3 + c;                                         \
         uint32_t w = b + threadIdx.x;                                                                        \
@@ -49,7 +60,7 @@ struct Stamp {
     }
 
 #define BENCH64(name, ASM)                                                                                   \
-    __global__ __launch_bounds__(256) void name(uint32_t* out, Stamp* stamps, uint32_t a, uint32_t b) {      \
+    __global__ __launch_bounds__(256) void name(uint32_t* out, Stamp* stamps, unsigned* gate, uint32_t a, uint32_t b) { \
         unsigned long long v[CH];                                                                            \
         for (int c = 0; c < CH; c++) v[c] = ((unsigned long long)a << 20) + threadIdx.x * 3 + c;             \
         unsigned long long w = ((unsigned long long)b << 33) + threadIdx.x;                                  \
@@ -129,10 +140,14 @@ void run(const char* name, K kern, int instr_per_op, int waves_per_simd = 8) {
     hipEvent_t a, b;
     hipEventCreate(&a);
     hipEventCreate(&b);
-    kern<<<blocks, threads>>>(d, st, 5, 3);
+    unsigned* gate;
+    hipMalloc(&gate, 4);
+    hipMemset(gate, 0, 4);
+    kern<<<blocks, threads>>>(d, st, gate, 5, 3);
     hipDeviceSynchronize();
+    hipMemset(gate, 0, 4);
     hipEventRecord(a);
-    kern<<<blocks, threads>>>(d, st, 5, 3);
+    kern<<<blocks, threads>>>(d, st, gate, 5, 3);
     hipEventRecord(b);
     hipEventSynchronize(b);
     float ms;
@@ -140,30 +155,37 @@ void run(const char* name, K kern, int instr_per_op, int waves_per_simd = 8) {
     std::vector<Stamp> h(nw);
     hipMemcpy(h.data(), st, sizeof(Stamp) * nw, hipMemcpyDeviceToHost);
     std::vector<double> cyc(nw), clk(nw);
-    for (int i = 0; i < nw; i++) cyc[i] = (double)h[i].cyc, clk[i] = h[i].real ? (double)h[i].cyc / (double)h[i].real * 1e8 : 0.0;
+    unsigned long long first = ~0ull, last = 0ull;
+    for (int i = 0; i < nw; i++) {
+        cyc[i] = (double)h[i].cyc, clk[i] = h[i].real ? (double)h[i].cyc / (double)h[i].real * 1e8 : 0.0;
+        first = h[i].r0 < first ? h[i].r0 : first, last = h[i].r1 > last ? h[i].r1 : last;
+    }
     std::sort(cyc.begin(), cyc.end());
     std::sort(clk.begin(), clk.end());
     const double wave_cycles = cyc[nw / 2], sclk = clk[nw / 2];
     const double per_wave = (double)ITER * CH * instr_per_op;
-    // all waves_per_simd waves of a SIMD run their loops side by side: the SIMD issues waves_per_simd * per_wave instructions
-    // in one wave's loop time
+    // Lower bound: all waves_per_simd waves of a SIMD run their loops side by side for a wave's whole loop time.
+    // Upper bound: the SIMD needs the whole span from the first wave's start to the last wave's end for them (waves that
+    // were dispatched late, e.g. when the grid exactly fills the chip and a CU was full, stretch the span).
     const double cpi_stamp = wave_cycles / (waves_per_simd * per_wave);
-    const double cpi_wall = ms * 1e-3 * sclk / (waves_per_simd * per_wave);
-    printf("%-14s w/SIMD %d  %8.3f ms  sclk %.3f GHz  %5.2f cyc/inst/SIMD (s_memtime)  %5.2f (wall x measured clock)\n", name,
-           waves_per_simd, ms, sclk * 1e-9, cpi_stamp, cpi_wall);
-    char buf[256];
-    snprintf(buf, sizeof buf, "%s\"%s@%d\": {\"cycles\": %.3f, \"cycles_wall\": %.3f, \"sclk_ghz\": %.4f, \"ms\": %.4f}",
-             g_json.empty() ? "" : ", ", name, waves_per_simd, cpi_stamp, cpi_wall, sclk * 1e-9, ms);
+    const double span_cycles = (double)(last - first) * 1e-8 * sclk;
+    const double cpi_span = span_cycles / (waves_per_simd * per_wave);
+    printf("%-14s w/SIMD %d  %8.3f ms  sclk %.3f GHz  cyc/inst/SIMD: %5.2f (wave loop)  %5.2f (first start..last end)  overlap %.2f\n",
+           name, waves_per_simd, ms, sclk * 1e-9, cpi_stamp, cpi_span, wave_cycles / span_cycles);
+    char buf[320];
+    snprintf(buf, sizeof buf, "%s\"%s@%d\": {\"cycles\": %.3f, \"cycles_span\": %.3f, \"overlap\": %.3f, \"sclk_ghz\": %.4f, \"ms\": %.4f}",
+             g_json.empty() ? "" : ", ", name, waves_per_simd, cpi_stamp, cpi_span, wave_cycles / span_cycles, sclk * 1e-9, ms);
     g_json += buf;
     g_clocks.push_back(sclk);
     hipFree(d);
     hipFree(st);
+    hipFree(gate);
 }
 
 int main() {
 #define R(k) run(#k, k, 1)
     // controls first, at 8, 4, 2 and 1 waves per SIMD
-    for (int w : {8, 4, 2, 1}) {
+    for (int w : {8, 6, 4, 3, 2, 1}) {
         run("c_fma_f32", c_fma_f32, 1, w);
         run("c_add_f32", c_add_f32, 1, w);
         run("c_pk_fma_f32", c_pk_fma_f32, 1, w);
