@@ -196,15 +196,64 @@ static hipError_t launch_leap_unit(asm_handle* h, const asm_bucket& b, OutMap ou
     return launch_leap_unit_w<K, 6>(h, b, out, hint);
 }
 
-/* forward sweep + traceback/coverage for one width class with window W */
+static int ensure_todo(asm_handle* h, size_t n) {
+    if (h->todo_cap < n + 1) {
+        if (h->d_todo) (void)hipFree(h->d_todo);
+        h->d_todo = nullptr, h->todo_cap = 0;
+        HIPCHK(h, hipMalloc((void**)&h->d_todo, sizeof(uint32_t) * (n + 1)));
+        h->todo_cap = n + 1;
+    }
+    return ASM_OK;
+}
+
+/* Full-matrix Gotoh + traceback + coverage verdict (nw_trace_affine_kernel) over `count` slots of a bucket slice: the slots
+ * listed in d_list (bucket-slice indices), or slots 0..count-1 when d_list is null.  Scratch: 4 direction bits per cell. */
+static int cover_full_matrix(asm_handle* h, const asm_bucket& b, const asm_params* p, const uint4* planes, const uint32_t* lens,
+                             const uint32_t* order, long slice_lo, const uint32_t* d_list, int64_t count, const CoverArgs& ca) {
+    if (count <= 0) return ASM_OK;
+    const int rows = b.maxlen > 0 ? b.maxlen : 1, cols8 = (rows + 7) / 8;
+    const size_t per_pair = (size_t)rows * (size_t)cols8 * sizeof(uint32_t);
+    int64_t chunk = (int64_t)((size_t)(6ull << 30) / per_pair);
+    chunk = chunk < 64 ? 64 : chunk;
+    chunk = chunk > count ? count : chunk;
+    uint32_t* d_scratch = nullptr;
+    HIPCHK(h, hipMalloc((void**)&d_scratch, per_pair * (size_t)chunk));
+    int rc = ASM_OK;
+    for (int64_t lo = 0; lo < count && !rc; lo += chunk) {
+        const int64_t c = count - lo < chunk ? count - lo : chunk;
+        const dim3 grid((unsigned)((c + 63) / 64)), block(64);
+        /* without a list the chunk is a contiguous run of slots: shift the base pointers like cover_bucket does */
+        const uint4* pl = d_list ? planes : planes + lo;
+        const uint32_t* ln = d_list ? lens : lens + lo;
+        const uint32_t* od = (d_list || !order) ? order : order + lo;
+        const long base = d_list ? slice_lo : slice_lo + lo;
+        const uint32_t* list = d_list ? d_list + lo : nullptr;
+#define AFFINE_TRACE(W64, ROWS)                                                                                                  \
+    hipLaunchKernelGGL((nw_trace_affine_kernel<W64, ROWS>), grid, block, 0, h->stream, pl, ln, (long)c, (long)b.n, b.w4, (int)p->x, \
+                       (int)p->o, (int)p->e, d_scratch, cols8, list, od, base, ca)
+        if (b.maxlen <= 128) AFFINE_TRACE(2, 128);
+        else if (b.maxlen <= 256) AFFINE_TRACE(4, 256);
+        else AFFINE_TRACE(8, 512);
+#undef AFFINE_TRACE
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
+            rc = fail(h, ASM_ENODEVICE, "asm_coverage: full-matrix traceback kernel failed");
+    }
+    (void)hipFree(d_scratch);
+    return rc;
+}
+
+/* forward sweep + traceback/coverage for one width class with window W; pairs the band cannot answer go through the
+ * full-matrix pass */
 template <int ND, int W>
-static int cover_bucket(asm_handle* h, const asm_bucket& b, const CoverArgs& ca) {
+static int cover_bucket(asm_handle* h, const asm_bucket& b, const asm_params* p, const CoverArgs& ca) {
     typedef typename TraceCell<W>::T Cell;
     if (b.n == 0) return ASM_OK;
     // scratch: [column][pair]; processed in slices of pairs so that it stays below ~6 GiB
     const int64_t cols = b.maxlen > 0 ? b.maxlen : 1;
     int64_t slice = (int64_t)(6ll << 30) / (cols * (int64_t)sizeof(Cell));
     slice = slice > b.n ? b.n : (slice < 4096 ? 4096 : slice);
+    int rc = ensure_todo(h, (size_t)slice);
+    if (rc) return rc;
     Cell* d_trace = nullptr;
     int32_t* d_band = nullptr;
     HIPCHK(h, hipMalloc((void**)&d_trace, (size_t)cols * (size_t)slice * sizeof(Cell)));
@@ -212,20 +261,25 @@ static int cover_bucket(asm_handle* h, const asm_bucket& b, const CoverArgs& ca)
         (void)hipFree(d_trace);
         return fail(h, ASM_ENOMEM, "asm_coverage: hipMalloc failed");
     }
-    int rc = ASM_OK;
     for (int64_t lo = 0; lo < b.n && !rc; lo += slice) {
         const int64_t cnt = b.n - lo < slice ? b.n - lo : slice;
         // a slice is addressed as a sub-batch: plane rows keep the bucket's stride, so pass shifted base pointers
         const uint4* planes = b.planes + lo;
         const uint32_t* lens = b.lens + lo;
         const uint32_t* order = b.order ? b.order + lo : nullptr;
+        uint32_t todo_count = 0;
+        if (hipMemsetAsync(h->d_todo, 0, sizeof(uint32_t), h->stream) != hipSuccess) rc = fail(h, ASM_ENODEVICE, "asm_coverage: memset failed");
         // the kernels index planes as [(p*w4+g)*n + i] with n = pairs of the BUCKET: use dedicated strided variants
         hipLaunchKernelGGL((nw_trace_forward_kernel<ND, W>), dim3(grid_for(cnt)), dim3(ASM_BLOCK), 0, h->stream, planes, lens,
                            (long)cnt, (long)b.n, b.w4, d_trace, d_band);
         hipLaunchKernelGGL((nw_trace_cover_kernel<ND / 2, W>), dim3(grid_for(cnt)), dim3(ASM_BLOCK), 0, h->stream, planes, lens,
-                           (long)cnt, (long)b.n, b.w4, (const Cell*)d_trace, (const int32_t*)d_band, order, lo, ca);
-        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess)
+                           (long)cnt, (long)b.n, b.w4, (const Cell*)d_trace, (const int32_t*)d_band, order, lo, ca, h->d_todo + 1,
+                           h->d_todo);
+        if (!rc && (hipGetLastError() != hipSuccess ||
+                    hipMemcpyAsync(&todo_count, h->d_todo, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                    hipStreamSynchronize(h->stream) != hipSuccess))
             rc = fail(h, ASM_ENODEVICE, "asm_coverage: kernel failed");
+        if (!rc && todo_count) rc = cover_full_matrix(h, b, p, planes, lens, order, lo, h->d_todo + 1, (int64_t)todo_count, ca);
     }
     (void)hipFree(d_trace);
     (void)hipFree(d_band);
@@ -1125,8 +1179,8 @@ int asm_coverage(asm_handle* h, const asm_batch* b, const asm_params* p, const u
                  uint8_t* d_nw_nops, unsigned long long* d_counters) {
     if (!h || !b || !p || !d_greedy_ops || !d_greedy_nops || !d_cover || !d_counters || greedy_cap < 1)
         return fail(h, ASM_EINVAL, "asm_coverage: bad argument");
-    if (p->x != 1 || p->o != 1 || p->e != 1)
-        return fail(h, ASM_EUNSUPPORTED, "asm_coverage: the NW traceback is built for unit penalties (x = o = e = 1) only");
+    int prc = check_params(h, ASM_NW, p, b->maxlen);
+    if (prc) return prc;
     if (window != 32 && window != 64) return fail(h, ASM_EINVAL, "asm_coverage: window must be 32 or 64");
     if (d_nw_ops && (!d_nw_nops || nw_cap < 1)) return fail(h, ASM_EINVAL, "asm_coverage: bad NW CIGAR buffers");
     if (b->n == 0) return ASM_OK;
@@ -1135,9 +1189,14 @@ int asm_coverage(asm_handle* h, const asm_batch* b, const asm_params* p, const u
     ca.g_ops = d_greedy_ops, ca.g_nops = d_greedy_nops, ca.g_cap = greedy_cap;
     ca.cover = d_cover, ca.nw_ops = d_nw_ops, ca.nw_nops = d_nw_nops, ca.nw_cap = nw_cap, ca.counters = d_counters;
     int rc = ASM_OK;
+    const bool unit = p->x == 1 && p->o == 1 && p->e == 1;
     for (int q = 0; q < b->nb && !rc; q++) {
         const asm_bucket& k = b->bk[q];
-#define COVER(ND) rc = window == 32 ? cover_bucket<ND, 32>(h, k, ca) : cover_bucket<ND, 64>(h, k, ca)
+        if (!unit) { /* general penalties: every pair through the full matrix */
+            rc = cover_full_matrix(h, k, p, k.planes, k.lens, k.order, 0, nullptr, k.n, ca);
+            continue;
+        }
+#define COVER(ND) rc = window == 32 ? cover_bucket<ND, 32>(h, k, p, ca) : cover_bucket<ND, 64>(h, k, p, ca)
         switch (k.w4) {
             case 1: COVER(4); break;
             case 2: COVER(8); break;

@@ -15,8 +15,12 @@
 //      positions of '=' runs of length >= 3 (LCM2).  LCM1 comes from the Greedy CIGAR row of the same pair (every 'M'
 //      run: Greedy writes matches and mismatches alike as M), and covers() is the leftmost subsequence test on the
 //      read's characters at those positions.
-// A pair is answered only when its banded distance leaves a margin of two diagonals to the band edge (the traceback
-// inspects neighbours of the optimal path); otherwise its flag is 2 = "not determined" and it is counted separately.
+// The banded pass answers a pair only when its distance leaves a margin of two diagonals to the band edge (the traceback
+// inspects neighbours of the optimal path).  Every other pair — and EVERY pair when (x, o, e) != (1, 1, 1) — goes through
+//   3. nw_trace_affine_kernel  — the full Gotoh matrix (any penalties, any distance) with four direction bits per cell
+//      (H came from the diagonal / H equals E / E extends / F extends) in a scratch array [row][8 cells][pair], then the
+//      oracle's traceback rule by rule: in H prefer the diagonal, then E ('D'), then F ('I'); inside a gap prefer extending.
+// so that no pair the harness covers (benchmark_utils.h:214-225,256-258) is left "not determined".
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -131,6 +135,69 @@ struct CoverArgs {
     unsigned long long* counters; /* [0] += covered, [1] += undetermined */
 };
 
+// covers(LCM(read, Greedy CIGAR, 1), LCM(read, NW CIGAR, 3)) given the read positions of the NW side's long '=' runs
+// (benchmark_coverage.h:26-67,73-91)
+template <int W64>
+ASM_DEV int cover_verdict(const VW<W64>& A0, const VW<W64>& A1, int m, const VW<W64>& lcm2, const CoverArgs& ca, long pair) {
+    // LCM1: read positions under Greedy's 'M' runs (benchmark_coverage.h:37-62 with threshold 1)
+    VW<W64> lcm1;
+#pragma unroll
+    for (int q = 0; q < W64; q++) lcm1.w[q] = 0ull;
+    const int gn = ca.g_nops[pair] < ca.g_cap ? ca.g_nops[pair] : ca.g_cap;
+    int ridx = 0;
+    for (int t = 0; t < gn; t++) {
+        const uint16_t e = ca.g_ops[pair * ca.g_cap + t];
+        const int cnt = e >> 3, op = e & 7;
+        if (op == 0) {
+            const int lim = ridx + cnt > m ? (m > ridx ? m - ridx : 0) : cnt; /* never read past the string */
+            vw_or_range<W64>(lcm1, ridx, lim);
+            ridx += cnt;
+        } else if (op == 1) {
+            ridx += cnt;
+        }
+    }
+    int n1 = 0, n2 = 0;
+    bool subset = true;
+#pragma unroll
+    for (int q = 0; q < W64; q++) {
+        n1 += __popcll(lcm1.w[q]), n2 += __popcll(lcm2.w[q]);
+        subset = subset && ((lcm2.w[q] & ~lcm1.w[q]) == 0ull);
+    }
+    bool cov;
+    if (n1 < n2) {
+        cov = false; /* benchmark_coverage.h:78-80 */
+    } else if (subset) {
+        cov = true; /* the same read positions serve as the embedding */
+    } else {
+        // leftmost subsequence test (benchmark_coverage.h:81-90) on per-base candidate vectors
+        VW<W64> pc[4];
+#pragma unroll
+        for (int q = 0; q < W64; q++) {
+            pc[0].w[q] = lcm1.w[q] & ~A0.w[q] & ~A1.w[q];
+            pc[1].w[q] = lcm1.w[q] & A0.w[q] & ~A1.w[q];
+            pc[2].w[q] = lcm1.w[q] & ~A0.w[q] & A1.w[q];
+            pc[3].w[q] = lcm1.w[q] & A0.w[q] & A1.w[q];
+        }
+        cov = true;
+        int cursor = 0, p2 = vw_next_one<W64>(lcm2, 0);
+        while (p2 < W64 * 64) {
+            const uint32_t code = vw_bit<W64>(A0, p2) | (vw_bit<W64>(A1, p2) << 1);
+            VW<W64> cand;
+#pragma unroll
+            for (int q = 0; q < W64; q++)
+                cand.w[q] = code == 0 ? pc[0].w[q] : code == 1 ? pc[1].w[q] : code == 2 ? pc[2].w[q] : pc[3].w[q];
+            const int p1 = vw_next_one<W64>(cand, cursor);
+            if (p1 >= W64 * 64) {
+                cov = false;
+                break;
+            }
+            cursor = p1 + 1;
+            p2 = vw_next_one<W64>(lcm2, p2 + 1);
+        }
+    }
+    return cov ? COVER_YES : COVER_NO;
+}
+
 template <int W64, int W>
 __global__ __launch_bounds__(ASM_BLOCK) void nw_trace_cover_kernel(const uint4* __restrict__ planes,
                                                                    const uint32_t* __restrict__ lens, long cnt,
@@ -138,7 +205,9 @@ __global__ __launch_bounds__(ASM_BLOCK) void nw_trace_cover_kernel(const uint4* 
                                                                    const typename TraceCell<W>::T* __restrict__ trace,
                                                                    const int32_t* __restrict__ band_result,
                                                                    const uint32_t* __restrict__ order, long slice_lo,
-                                                                   CoverArgs ca) {
+                                                                   CoverArgs ca, uint32_t* __restrict__ todo /* slice slots the band
+                                                                   could not answer, for the full-matrix pass; null: flag them 2 */,
+                                                                   uint32_t* __restrict__ todo_count) {
     typedef typename BandWord<W>::T WT;
     constexpr int C = W / 2;
     __shared__ unsigned int s_part[4];
@@ -255,72 +324,178 @@ __global__ __launch_bounds__(ASM_BLOCK) void nw_trace_cover_kernel(const uint4* 
         }
         // ---------------- coverage ----------------
         int flag = COVER_UNKNOWN;
-        if (ok) {
-            // LCM1: read positions under Greedy's 'M' runs (benchmark_coverage.h:37-62 with threshold 1)
-            VW<W64> lcm1;
-#pragma unroll
-            for (int q = 0; q < W64; q++) lcm1.w[q] = 0ull;
-            const int gn = ca.g_nops[pair] < ca.g_cap ? ca.g_nops[pair] : ca.g_cap;
-            int ridx = 0;
-            for (int t = 0; t < gn; t++) {
-                const uint16_t e = ca.g_ops[pair * ca.g_cap + t];
-                const int cnt = e >> 3, op = e & 7;
-                if (op == 0) {
-                    const int lim = ridx + cnt > m ? (m > ridx ? m - ridx : 0) : cnt; /* never read past the string */
-                    vw_or_range<W64>(lcm1, ridx, lim);
-                    ridx += cnt;
-                } else if (op == 1) {
-                    ridx += cnt;
-                }
-            }
-            int n1 = 0, n2 = 0;
-            bool subset = true;
-#pragma unroll
-            for (int q = 0; q < W64; q++) {
-                n1 += __popcll(lcm1.w[q]), n2 += __popcll(lcm2.w[q]);
-                subset = subset && ((lcm2.w[q] & ~lcm1.w[q]) == 0ull);
-            }
-            bool cov;
-            if (n1 < n2) {
-                cov = false; /* benchmark_coverage.h:78-80 */
-            } else if (subset) {
-                cov = true; /* the same read positions serve as the embedding */
-            } else {
-                // leftmost subsequence test (benchmark_coverage.h:81-90) on per-base candidate vectors
-                VW<W64> pc[4];
-#pragma unroll
-                for (int q = 0; q < W64; q++) {
-                    pc[0].w[q] = lcm1.w[q] & ~A0.w[q] & ~A1.w[q];
-                    pc[1].w[q] = lcm1.w[q] & A0.w[q] & ~A1.w[q];
-                    pc[2].w[q] = lcm1.w[q] & ~A0.w[q] & A1.w[q];
-                    pc[3].w[q] = lcm1.w[q] & A0.w[q] & A1.w[q];
-                }
-                cov = true;
-                int cursor = 0, p2 = vw_next_one<W64>(lcm2, 0);
-                while (p2 < W64 * 64) {
-                    const uint32_t code = vw_bit<W64>(A0, p2) | (vw_bit<W64>(A1, p2) << 1);
-                    VW<W64> cand;
-#pragma unroll
-                    for (int q = 0; q < W64; q++)
-                        cand.w[q] = code == 0 ? pc[0].w[q] : code == 1 ? pc[1].w[q] : code == 2 ? pc[2].w[q] : pc[3].w[q];
-                    const int p1 = vw_next_one<W64>(cand, cursor);
-                    if (p1 >= W64 * 64) {
-                        cov = false;
-                        break;
-                    }
-                    cursor = p1 + 1;
-                    p2 = vw_next_one<W64>(lcm2, p2 + 1);
-                }
-            }
-            flag = cov ? COVER_YES : COVER_NO;
-        }
+        if (ok) flag = cover_verdict<W64>(A0, A1, m, lcm2, ca, pair);
         ca.cover[pair] = (uint8_t)flag;
         if (ca.nw_nops) ca.nw_nops[pair] = (uint8_t)(ok ? (nops > 255 ? 255 : nops) : 0);
         covered = flag == COVER_YES, unknown = flag == COVER_UNKNOWN;
+    }
+    if (todo != nullptr) { /* wave-aggregated append: one atomic per wave */
+        const u64 bal = __ballot(unknown != 0u);
+        if (bal) {
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            const int leader = __builtin_ctzll(bal);
+            uint32_t base = 0;
+            if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(todo_count, (uint32_t)__builtin_popcountll(bal));
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+            if (unknown) todo[base + rank] = (uint32_t)i;
+        }
+        unknown = 0; /* the full-matrix pass answers them */
     }
     const unsigned int tc = block_sum_256(covered, s_part), tu = block_sum_256(unknown, s_part);
     if (threadIdx.x == 0) {
         if (tc) atomicAdd(&ca.counters[0], (unsigned long long)tc);
         if (tu) atomicAdd(&ca.counters[1], (unsigned long long)tu);
     }
+}
+
+// --------------------------------------------------------------------------------------------------------
+// Full-matrix Gotoh with traceback and coverage verdict, any (x, o, e), any distance.  One thread per pair; the forward sweep is
+// nw_affine_kernel's (column blocks of 32 in registers, block boundary column through LDS) and additionally records, per
+// cell, the four facts the oracle's traceback asks for (oracle/asm_oracle.c, orc_nw_cigar_batch):
+//   bit 0  H == H[i-1][j-1] + sub      bit 1  H == E      bit 2  E == E[i][j-1] + e      bit 3  F == F[i-1][j] + e
+// packed 8 cells per dword in scratch[((i-1) * cols8 + (j-1)/8) * stride + slot] (coalesced across the pairs of a wave).
+// --------------------------------------------------------------------------------------------------------
+template <int W64, int MAXROWS>
+__global__ __launch_bounds__(64) void nw_trace_affine_kernel(const uint4* __restrict__ planes, const uint32_t* __restrict__ lens,
+                                                             long cnt /* slots of this launch */, long n /* plane stride */, int w4,
+                                                             int x, int o, int e, uint32_t* __restrict__ scratch, int cols8,
+                                                             const uint32_t* __restrict__ todo /* cnt bucket slots, or null: slots 0..cnt-1 */,
+                                                             const uint32_t* __restrict__ order, long slice_lo, CoverArgs ca) {
+    __shared__ uint32_t s_bound[MAXROWS + 1][64];
+    __shared__ unsigned int s_cov[1];
+    const int t = threadIdx.x;
+    const long slot = (long)blockIdx.x * 64 + t;
+    const long stride = cnt;
+    if (t == 0) s_cov[0] = 0u;
+    __syncthreads();
+    unsigned int covered = 0u;
+    if (slot < stride) {
+        const long i = todo ? (long)todo[slot] : slot;
+        const long pair = order ? (long)order[i] : slice_lo + i;
+        const uint32_t ln = lens[i];
+        const int m = (int)(ln & 0xffffu), nn = (int)(ln >> 16);
+        VW<W64> A0, A1, B0, B1;
+        load_planes<W64>(planes, n, w4, i, A0, A1, B0, B1);
+        // ---------------- forward ----------------
+        for (int j0 = 0; j0 < nn; j0 += NW_CB) {
+            uint32_t tb0 = 0, tb1 = 0;
+#pragma unroll
+            for (int q = 0; q < W64; q++) {
+                if ((j0 >> 6) == q) {
+                    tb0 = (uint32_t)(B0.w[q] >> (j0 & 63));
+                    tb1 = (uint32_t)(B1.w[q] >> (j0 & 63));
+                }
+            }
+            int H[NW_CB], F[NW_CB];
+#pragma unroll
+            for (int jj = 0; jj < NW_CB; jj++) {
+                H[jj] = o + (j0 + jj) * e; /* H[0][j], j = j0+jj+1 */
+                F[jj] = NW_BIG;
+            }
+            int diag = j0 == 0 ? 0 : o + (j0 - 1) * e; /* H[0][j0] */
+            for (int r = 1; r <= m; r++) {
+                uint32_t a0 = 0, a1 = 0;
+#pragma unroll
+                for (int q = 0; q < W64; q++) {
+                    if (((r - 1) >> 6) == q) {
+                        a0 = (uint32_t)(A0.w[q] >> ((r - 1) & 63)) & 1u;
+                        a1 = (uint32_t)(A1.w[q] >> ((r - 1) & 63)) & 1u;
+                    }
+                }
+                const uint32_t mm = (tb0 ^ (0u - a0)) | (tb1 ^ (0u - a1));
+                int hleft, eleft;
+                if (j0 == 0) {
+                    hleft = o + (r - 1) * e; /* H[r][0] */
+                    eleft = NW_BIG;
+                } else {
+                    const uint32_t pk = s_bound[r][t];
+                    hleft = (int)(pk & 0xffffu);
+                    eleft = (int)(pk >> 16);
+                }
+                const int next_diag = hleft;
+                uint32_t bits[NW_CB / 8];
+#pragma unroll
+                for (int q = 0; q < NW_CB / 8; q++) bits[q] = 0u;
+#pragma unroll
+                for (int jj = 0; jj < NW_CB; jj++) {
+                    const int up = H[jj];
+                    const int fext = F[jj] + e;
+                    int f = up + o < fext ? up + o : fext;
+                    const int eext = eleft + e;
+                    int ee = hleft + o < eext ? hleft + o : eext;
+                    const int dg = diag + (((mm >> jj) & 1u) ? x : 0);
+                    int h = dg < f ? dg : f;
+                    h = ee < h ? ee : h;
+                    const uint32_t nib = (h == dg ? 1u : 0u) | (h == ee ? 2u : 0u) | (ee == eext ? 4u : 0u) | (f == fext ? 8u : 0u);
+                    bits[jj >> 3] |= nib << (4 * (jj & 7));
+                    f = f > NW_BIG ? NW_BIG : f;
+                    ee = ee > NW_BIG ? NW_BIG : ee;
+                    diag = up;
+                    H[jj] = h, F[jj] = f;
+                    hleft = h, eleft = ee;
+                }
+                diag = next_diag;
+                s_bound[r][t] = (uint32_t)hleft | ((uint32_t)eleft << 16);
+#pragma unroll
+                for (int q = 0; q < NW_CB / 8; q++)
+                    if (j0 + 8 * q < nn) scratch[((long)(r - 1) * cols8 + (j0 >> 3) + q) * stride + slot] = bits[q];
+            }
+        }
+        // ---------------- traceback (oracle/asm_oracle.c orc_nw_cigar_batch, rule by rule) ----------------
+        VW<W64> lcm2;
+#pragma unroll
+        for (int q = 0; q < W64; q++) lcm2.w[q] = 0ull;
+        int nops = 0, cur_op = -1, cur_cnt = 0;
+        int ii = m, j = nn, state = 0; /* 0 = H, 1 = E ('D'), 2 = F ('I') */
+        auto flush = [&]() {
+            if (cur_cnt > 0) {
+                if (cur_op == 3 && cur_cnt >= 3) vw_or_range<W64>(lcm2, ii, cur_cnt); /* '=' run: read [ii, ii+cnt) */
+                if (ca.nw_ops && nops < ca.nw_cap) ca.nw_ops[pair * ca.nw_cap + nops] = (uint16_t)((cur_cnt << 3) | cur_op);
+                nops++;
+            }
+            cur_cnt = 0;
+        };
+        auto emit = [&](int op) {
+            if (op != cur_op) {
+                flush();
+                cur_op = op;
+            }
+            cur_cnt++;
+        };
+        for (int guard = 0; guard < 2 * ASM_MAX_LENGTH + 4 && (ii > 0 || j > 0); guard++) {
+            uint32_t nib = 0u;
+            if (ii > 0 && j > 0) nib = (scratch[((long)(ii - 1) * cols8 + ((j - 1) >> 3)) * stride + slot] >> (4 * ((j - 1) & 7))) & 15u;
+            if (state == 0) {
+                if (ii > 0 && j > 0 && (nib & 1u)) {
+                    const bool match = ((vw_bit<W64>(A0, ii - 1) ^ vw_bit<W64>(B0, j - 1)) |
+                                        (vw_bit<W64>(A1, ii - 1) ^ vw_bit<W64>(B1, j - 1))) == 0u;
+                    emit(match ? 3 : 4);
+                    ii--, j--;
+                } else if (j > 0 && (ii == 0 || (nib & 2u))) {
+                    state = 1; /* H == E; on row 0 H is E by construction */
+                } else {
+                    state = 2;
+                }
+            } else if (state == 1) {
+                emit(2); /* 'D' */
+                /* E[i][j] == E[i][j-1] + e, j > 1: on row 0 E[0][j] = o + (j-1) e, so always */
+                const bool ext = j > 1 && (ii == 0 || (nib & 4u));
+                if (!ext) state = 0;
+                j--;
+            } else {
+                emit(1); /* 'I' */
+                const bool ext = ii > 1 && (j == 0 || (nib & 8u));
+                if (!ext) state = 0;
+                ii--;
+            }
+        }
+        flush();
+        const int flag = cover_verdict<W64>(A0, A1, m, lcm2, ca, pair);
+        ca.cover[pair] = (uint8_t)flag;
+        if (ca.nw_nops) ca.nw_nops[pair] = (uint8_t)(nops > 255 ? 255 : nops);
+        covered = flag == COVER_YES;
+    }
+    if (covered) atomicAdd(&s_cov[0], 1u);
+    __syncthreads();
+    if (t == 0 && s_cov[0]) atomicAdd(&ca.counters[0], (unsigned long long)s_cov[0]);
 }

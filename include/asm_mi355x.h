@@ -175,10 +175,13 @@ int asm_cigar_format(const uint16_t* ops, int nops, int cap, char* out, size_t o
 /* The harness's coverage counter (benchmark_utils.h:214-225,256-258; benchmark_coverage.h:26-91): for every pair,
  * does LCM(read, Greedy CIGAR, threshold 1) cover LCM(read, NW CIGAR, threshold 3)?  Needs the Greedy CIGAR rows of
  * asm_greedy_cigar_batch_async.  The NW alignment is traced back on the device with this library's own documented
- * preference (diagonal, then gap in the read, then gap in the reference — parasail's is internal and unpinned); unit
- * penalties only.  `window` = 32 or 64 rows of banded DP: pairs whose distance is above window/2 - 3 get flag 2.
- * d_cover[i] = 1 covers / 0 does not / 2 not determined; d_counters[0] += covered, d_counters[1] += not determined.
- * d_nw_ops (optional) receives the NW CIGAR rows in traceback (reverse) order, entries as above.  Synchronous. */
+ * preference (in H the diagonal, then a gap in the read 'D', then a gap in the reference 'I'; inside a gap, extending it —
+ * parasail's is internal and unpinned), for any penalties p->x, p->o, p->e the NW aligner accepts.  Unit penalties run a
+ * banded bit-parallel pass with `window` = 32 or 64 rows first; pairs it cannot answer (distance above window/2 - 3) and
+ * every pair under other penalties go through a full Gotoh matrix with stored directions, so every pair gets an answer:
+ * d_cover[i] = 1 covers / 0 does not (2 = not determined is no longer produced); d_counters[0] += covered,
+ * d_counters[1] += not determined (stays 0).  d_nw_ops (optional) receives the NW CIGAR rows in traceback (reverse) order,
+ * entries as above.  Synchronous. */
 int asm_coverage(asm_handle* h, const asm_batch* b, const asm_params* p, const uint16_t* d_greedy_ops, int greedy_cap,
                  const uint8_t* d_greedy_nops, int window, uint8_t* d_cover, uint16_t* d_nw_ops, int nw_cap,
                  uint8_t* d_nw_nops, unsigned long long* d_counters);

@@ -102,6 +102,14 @@ int orc_simd_ed_batch(int64_t n, const char* reads, const uint32_t* read_off, co
 int orc_shd_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
                   int max_error, int32_t* pass);
 
+/* ---- the reference's input distribution: asm_oracle_dataset.c ----------------------------------------------------------
+ * Dataset(n, length, error_rate, mismatch_rate, exact = true).output() (GASMA/benchmark/benchmark_dataset.h:85-187,212-240) over
+ * an emulation of glibc's rand() seeded with srand(seed) — the stream the README's accuracy lines are statistics of.
+ * reads: n*length bytes; refs: n*(length + ceil(length*error_rate) + 1) bytes; offsets n+1 each. */
+int orc_reference_dataset(int64_t n, int length, float error_rate, float mismatch_rate, unsigned int seed, char* reads,
+                          uint32_t* read_off, char* refs, uint32_t* ref_off);
+void orc_glibc_rand_stream(unsigned int seed, int count, int32_t* out);
+
 /* number of OpenMP threads the batch entry points will use (LEAP/NW/Greedy-clean are parallel over pairs;
  * Greedy-sequential resolves views serially first, then runs pairs in parallel). */
 int orc_set_threads(int nthreads);

@@ -10,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "libasm_oracle.so")
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libasm_ref.so")
 REF_SIMD_SO = os.path.join(ROOT, "oracle", "_ref", "libasm_ref_simd.so")
+REF_DATASET = os.path.join(ROOT, "oracle", "_ref", "ref_dataset")  # the reference's own Dataset generator with a settable seed
 # state the reference harness pins before a batch (its warm-up pair): final_ED, lane distance, converge_ED
 SIMD_WARM_STATE = (1, 1, 2)
 CIGAR_STRIDE = 768
@@ -128,6 +129,28 @@ class Oracle:
                 c = fin[side * 128 + tail_slot_after(s, hb.n)]
                 if c != 0xEE:
                     out[side * 128 + s] = base_code(c)
+        return out
+
+    def reference_dataset(self, n, length, err, seed, mismatch_rate=0.96):
+        """Pairs drawn the reference's way (oracle/asm_oracle_dataset.c: Dataset over glibc's rand() after srand(seed)) as a
+        batch in the C ABI's layout (arrays are what approximate_string_matching_amd.HostBatch holds)."""
+        import math
+
+        cap = n * (length + int(math.ceil(length * float(np.float32(err)))) + 2) + 16
+        reads = np.zeros(n * length + 16, np.uint8)
+        refs = np.zeros(cap, np.uint8)
+        ro = np.zeros(n + 1, np.uint32)
+        fo = np.zeros(n + 1, np.uint32)
+        self.lib.orc_reference_dataset.argtypes = [_i64, _i, ctypes.c_float, ctypes.c_float, ctypes.c_uint, _vp, _vp, _vp, _vp]
+        rc = self.lib.orc_reference_dataset(n, length, err, mismatch_rate, seed, reads.ctypes.data, ro.ctypes.data, refs.ctypes.data,
+                                            fo.ctypes.data)
+        assert rc == 0, rc
+        return reads[:int(ro[-1])], ro, refs[:int(fo[-1])], fo
+
+    def glibc_rand_stream(self, seed, count):
+        out = np.zeros(count, np.int32)
+        self.lib.orc_glibc_rand_stream.argtypes = [ctypes.c_uint, _i, _vp]
+        self.lib.orc_glibc_rand_stream(seed, count, out.ctypes.data)
         return out
 
     def greedy_views(self, hb, mode):

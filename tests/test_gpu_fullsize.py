@@ -95,3 +95,41 @@ def test_error_free_batch_at_full_size(asm, engine):
     assert not engine.simd_ed(batch, 3, True, asm.FILTER_CLEAN).any()
     assert engine.shd_filter(batch, 3).all()
     batch.free()
+
+
+@pytest.mark.parametrize("err", [0.05, 0.10, 0.15, 0.20])
+def test_readme_accuracy_lines_from_the_device_counters(asm, engine, oracle, err):
+    """The reference's README.md:16-20,32-36,47-51,63-67 — 10^6 simulated 100 bp pairs per error rate — re-run at that size
+    through `_run_benchmark` on the device (Greedy in sequential mode: the reference as run), percentages from the device
+    counters.  These four lines are all the reference holds about NW's results (parasail is absent): LEAP and Greedy accuracy
+    are "penalty == NW penalty", so a wrong NW distance moves both.  The pairs are drawn the reference's way
+    (oracle.reference_dataset = Dataset over glibc's rand(), byte-identical to the compiled reference generator): its
+    dependent pattern characters shift these percentages by ~0.2 points at err >= 0.15 against independent ones.
+    Tolerance: 4 binomial standard errors of the difference of two independent 10^6-pair samples.  Coverage (README's fourth
+    line) is compared too, at 0.25 points: its NW traceback tie-break is this library's, parasail's is not pinned."""
+    from tests.test_oracle_golden import README_ACCURACY, README_COVERAGE, readme_tolerance
+
+    n = 1_000_000
+    hb = asm.HostBatch(*oracle.reference_dataset(n, 100, err, seed=2000 + int(round(err * 100))))
+    params = asm.Params.default(k=3)
+    batch = engine.upload(hb, asm.GREEDY_SEQUENTIAL)
+    d = [engine.malloc(4 * n) for _ in range(3)]
+    d_cnt = engine.malloc(32)
+    engine.memset_async(d_cnt, 0, 32)
+    engine.run_benchmark_async(batch, params, d[0], d[1], d[2], d_cnt, repack=True)
+    cnt = engine.to_host(d_cnt, 8).view(np.uint64)[:4].astype(np.float64)
+    nw = engine.to_host(d[0], n)
+    for x in d + [d_cnt]:
+        engine.free(x)
+    assert int(cnt[0]) == n and int(cnt[1]) == n
+    edits = {0.05: 5, 0.10: 10, 0.15: 16, 0.20: 20}[err]   # benchmark_dataset.h:154: ceil(100 * 0.15f) = 16
+    assert int(nw.max()) <= edits
+    leap_pct, greedy_pct = 100.0 * cnt[2] / n, 100.0 * cnt[3] / n
+    want_leap, want_greedy = README_ACCURACY[err]
+    assert abs(leap_pct - want_leap) < readme_tolerance(want_leap, n), (err, leap_pct, want_leap)
+    assert abs(greedy_pct - want_greedy) < readme_tolerance(want_greedy, n), (err, greedy_pct, want_greedy)
+    cov = engine.coverage(batch, params, window=64)
+    assert cov["undetermined"] == 0
+    cov_pct = 100.0 * cov["covered"] / n
+    assert abs(cov_pct - README_COVERAGE[err]) < 0.25, (err, cov_pct, README_COVERAGE[err])
+    batch.free()

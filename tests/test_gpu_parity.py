@@ -324,29 +324,57 @@ def test_accuracy_counters(asm, engine, oracle):
         engine.free(p)
 
 
-@pytest.mark.parametrize("wl,n,window", [("C2", 20000, 32), ("C2", 6000, 64), ("C1", 6000, 32), ("C4", 10000, 32),
-                                         ("C5", 8000, 64), ("C3", 3000, 64)])
-def test_coverage_counter_and_nw_traceback(asm, engine, oracle, wl, n, window):
+@pytest.mark.parametrize("wl,n,window,err", [("C2", 20000, 32, None), ("C2", 6000, 64, None), ("C1", 6000, 32, None),
+                                             ("C4", 10000, 32, None), ("C5", 8000, 64, None), ("C3", 3000, 64, None),
+                                             ("C2", 4000, 32, 0.30), ("C5", 3000, 32, 0.25)])
+def test_coverage_counter_and_nw_traceback(asm, engine, oracle, wl, n, window, err):
     """The [Coverage] line of the harness (benchmark_utils.h:214-225,256-258) on the device: NW traceback with the
-    oracle's documented tie-break, LCM strings, covers().  Compared pair by pair with the oracle."""
+    oracle's documented tie-break, LCM strings, covers().  Compared pair by pair with the oracle — EVERY pair: what the
+    banded pass cannot answer (distance above window/2 - 3: most pairs of the noisy cases) goes through the full matrix."""
     cfg, _, _ = asm.workload(wl)
+    if err is not None:
+        cfg.err = err
     hb = asm.generate_pairs(cfg, 9, n)
     params = asm.Params.default(k=3)
     batch = engine.upload(hb, asm.GREEDY_CLEAN)
-    got = engine.coverage(batch, params, window=window, cap=96, want_nw_cigars=True)
+    got = engine.coverage(batch, params, window=window, cap=192, want_nw_cigars=True)
     gcost, gcig = oracle.greedy(hb, k=3, mode=1, cigars=True)
     pen, ncig = oracle.nw_cigar(hb)
     want = oracle.coverage(hb, gcig, 1, ncig, 3)
-    det = got["cover"] != 2
-    limit = window // 2 - 3
-    assert np.array_equal(det, pen <= limit), "pairs are answered exactly when the distance leaves the band margin"
-    assert got["undetermined"] == int((~det).sum()) and got["covered"] == int((got["cover"] == 1).sum())
-    bad = np.nonzero(det & (got["cover"] != want))[0]
-    assert bad.size == 0, (bad[:5], got["cover"][bad[:5]], want[bad[:5]])
-    wrong = [i for i in np.nonzero(det)[0] if got["nw_cigars"][i] != ncig[i]]
-    assert not wrong, (len(wrong), got["nw_cigars"][wrong[0]], ncig[wrong[0]])
-    if wl == "C2":
-        assert det.all() and 0.90 < want.mean() < 0.99  # README.md:36 reports 94.2 % with parasail's traceback
+    assert got["undetermined"] == 0 and not (got["cover"] == 2).any()
+    assert got["covered"] == int((got["cover"] == 1).sum())
+    if err is not None:
+        assert (pen > window // 2 - 3).mean() > 0.3          # the fallback really ran on a large share
+    bad = np.nonzero(got["cover"] != want)[0]
+    assert bad.size == 0, (bad[:5], got["cover"][bad[:5]], want[bad[:5]], pen[bad[:5]])
+    wrong = [i for i in range(n) if got["nw_cigars"][i] != ncig[i]]
+    assert not wrong, (len(wrong), pen[wrong[0]], got["nw_cigars"][wrong[0]], ncig[wrong[0]])
+    if wl == "C2" and err is None:
+        assert 0.90 < want.mean() < 0.99  # README.md:36 reports 94.2 % with parasail's traceback
+
+
+@pytest.mark.parametrize("x,o,e", [(2, 3, 1), (4, 6, 2), (1, 2, 1), (3, 1, 1), (1, 1, 0), (0, 2, 1)])
+def test_coverage_with_general_penalties(asm, engine, oracle, x, o, e):
+    """benchmark_utils.h:214-225 computes coverage for whatever (x, o, e) the harness was built with: affine traceback on the
+    device (full Gotoh matrix with stored directions), CIGAR for CIGAR and verdict for verdict against the oracle; 100 bp,
+    mixed 64-300 bp and ragged 0-250 bp batches."""
+    from tests.util import random_ragged_batch as ragged
+
+    k = 3
+    for name, hb in (("C2", asm.generate_pairs(asm.workload("C2")[0], 41, 3000)), ("C5", asm.generate_pairs(asm.workload("C5")[0], 43, 1500)),
+                     ("ragged", ragged(asm, 47, 800, 0, 250))):
+        params = asm.Params.default(k=k, x=x, o=o, e=e)
+        batch = engine.upload(hb, asm.GREEDY_CLEAN)
+        got = engine.coverage(batch, params, window=64, cap=255, want_nw_cigars=True)
+        gcost, gcig = oracle.greedy(hb, k, x, o, e, mode=1, cigars=True)
+        pen, ncig = oracle.nw_cigar(hb, x, o, e)
+        want = oracle.coverage(hb, gcig, 1, ncig, 3)
+        assert got["undetermined"] == 0
+        wrong = [i for i in range(hb.n) if got["nw_cigars"][i] != ncig[i]]
+        assert not wrong, (name, len(wrong), hb.pair(wrong[0]), got["nw_cigars"][wrong[0]], ncig[wrong[0]])
+        bad = np.nonzero(got["cover"] != want)[0]
+        assert bad.size == 0, (name, bad[:5], got["cover"][bad[:5]], want[bad[:5]])
+        assert np.array_equal(got["greedy_cost"], gcost)
 
 
 def test_leap_work_hint_changes_schedule_not_results(asm, engine, oracle):

@@ -1,5 +1,7 @@
 """Pins the oracle against the REAL reference compiled in place (oracle/_ref/libasm_ref.so).  That library exists only
 where /root/reference does (this container); elsewhere these tests skip and the committed goldens carry the pin."""
+import os
+
 import numpy as np
 import pytest
 
@@ -110,3 +112,22 @@ def test_semi_global_oracle_equals_reference(asm, oracle, ref, wl, n, k, pen):
         assert all(a == b for a, b, d in zip(ocig, rcig, gd) if d), (wl, k, pen, mode, "CIGAR")
         differs += int((oc != oracle.greedy(hb, k, *pen, mode=mode)).sum())
     assert differs > 0, "SEMI_GLOBAL must change some costs"
+
+
+def test_input_distribution_restatement_matches_the_reference_generator(asm, oracle, tmp_path):
+    """oracle/asm_oracle_dataset.c (Dataset's procedure over an emulated glibc rand()) against the reference's own `Dataset`
+    compiled in place (oracle/_ref/ref_dataset: benchmark_dataset.h #included, time() supplied so that the seed is known):
+    the .seq files are byte-for-byte equal, for every README error rate incl. the 100 * 0.15f -> 16 edits quirk (:154)."""
+    import subprocess
+
+    from tests import oracle_binding as ob
+
+    if not os.path.exists(ob.REF_DATASET):
+        pytest.skip("oracle/_ref/ref_dataset is built only where /root/reference exists")
+    for seed, n, length, err in ((777, 3000, 100, 0.15), (5, 2000, 100, 0.05), (123456, 1500, 150, 0.20), (99, 1000, 64, 0.10)):
+        path = tmp_path / f"ref_{seed}.seq"
+        subprocess.check_call([ob.REF_DATASET, str(seed), str(n), str(length), str(err), str(path)])
+        want = asm.HostBatch.read_seq_file(str(path))
+        reads, ro, refs, fo = oracle.reference_dataset(n, length, err, seed)
+        assert np.array_equal(ro, want.read_off) and np.array_equal(fo, want.ref_off)
+        assert np.array_equal(reads, want.reads) and np.array_equal(refs, want.refs)
