@@ -54,6 +54,14 @@ class Params(ctypes.Structure):
         return cls(k, x, o, e, p_match, p_mismatch, p_indel, alignment_type, 0)
 
 
+class StreamStats(ctypes.Structure):
+    """asm_stream_stats: what asm_stream_seq_file did."""
+
+    _fields_ = [("pairs", ctypes.c_int64), ("chunks", ctypes.c_int64), ("bytes", ctypes.c_int64),
+                ("counters", ctypes.c_ulonglong * 4), ("seconds", ctypes.c_double), ("seconds_read", ctypes.c_double),
+                ("max_length", ctypes.c_int32), ("reserved_", ctypes.c_int32)]
+
+
 class GenConfig(ctypes.Structure):
     """asm_gen_config: seeded restatement of `Dataset` (benchmark_dataset.h:61-253)."""
 
@@ -122,6 +130,9 @@ def load_library() -> ctypes.CDLL:
         "asm_reference_free": (i32, [vp, vp]),
         "asm_batch_from_hits": (i32, [vp, vp, i64, vp, vp, vp, i32, c.POINTER(vp)]),
         "asm_batch_free": (i32, [vp, vp]),
+        "asm_batch_from_text": (i32, [vp, vp, c.c_size_t, i32, c.POINTER(vp)]),
+        "asm_stream_seq_file": (i32, [vp, c.c_char_p, c.POINTER(Params), i32, i32, i64, i64, vp, vp, vp, i64, vp, i64,
+                                      c.POINTER(StreamStats)]),
         "asm_batch_tail_summary": (i32, [vp, vp, vp]),
         "asm_tail_state_advance": (i32, [vp, vp, i64]),
         "asm_batch_resolve_tails": (i32, [vp, vp, vp]),
@@ -346,6 +357,38 @@ class Engine:
         ptr = ctypes.c_void_p()
         self._chk(self.lib.asm_batch_generate(self.h, ctypes.byref(cfg), first, n, greedy_mode, ctypes.byref(ptr)))
         return DeviceBatch(self, ptr)
+
+    def batch_from_text(self, text, greedy_mode: int = GREEDY_CLEAN) -> DeviceBatch:
+        """asm_batch_from_text: a batch out of the harness's file format held in memory (bytes / uint8 array); the raw text
+        goes to the GPU as it is and is parsed there."""
+        buf = np.frombuffer(text.encode("ascii") if isinstance(text, str) else bytes(text), np.uint8) \
+            if not isinstance(text, np.ndarray) else np.ascontiguousarray(text, np.uint8)
+        ptr = ctypes.c_void_p()
+        self._chk(self.lib.asm_batch_from_text(self.h, buf.ctypes.data if buf.size else None, buf.size, greedy_mode,
+                                               ctypes.byref(ptr)))
+        return DeviceBatch(self, ptr)
+
+    def stream_seq_file(self, path: str, params: Params, greedy_mode: int = GREEDY_SEQUENTIAL,
+                        aligners: Sequence[int] = (NW, LEAP, GREEDY), chunk_bytes: int = 0, max_pairs: int = 0,
+                        capacity: Optional[int] = None, answers: Optional[np.ndarray] = None):
+        """asm_stream_seq_file: `benchmark::read_string_file` + `run` (benchmark_utils.h:325-385) for a file of any size, streamed
+        through pinned buffers with the parse, the pack and the aligners of one chunk overlapping the transfer of the next.
+        -> (dict aligner -> int32[pairs], StreamStats).  capacity: entries of the result arrays (default: an upper bound from
+        the file size; shorter reads need a larger bound, or max_pairs)."""
+        if capacity is None:
+            try:
+                capacity = max_pairs if max_pairs > 0 else os.path.getsize(path) // 4 + 16
+            except OSError:
+                capacity = 16  # the library reports the unreadable file (benchmark_utils.h:350 only prints)
+        mask = sum(1 << a for a in aligners)
+        out = {a: np.zeros(capacity, np.int32) for a in aligners}
+        st = StreamStats()
+        ans = None if answers is None else np.ascontiguousarray(answers, np.int32)
+        ptr = lambda a: out[a].ctypes.data if a in out else None  # noqa: E731
+        self._chk(self.lib.asm_stream_seq_file(self.h, path.encode(), ctypes.byref(params), greedy_mode, mask, chunk_bytes, max_pairs,
+                                               ptr(NW), ptr(LEAP), ptr(GREEDY), capacity, None if ans is None else ans.ctypes.data,
+                                               0 if ans is None else ans.size, ctypes.byref(st)))
+        return {a: v[:st.pairs] for a, v in out.items()}, st
 
     def upload_reference(self, text) -> "Reference":
         """Reference text (bytes / str / uint8 array) resident in HBM for seed-hit batches."""

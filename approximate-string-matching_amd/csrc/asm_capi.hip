@@ -8,7 +8,17 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <fcntl.h>
+#include <map>
+#include <mutex>
 #include <string>
+#include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/asm_mi355x.h"
@@ -19,6 +29,7 @@
 #include "asm_cover.h"
 #include "asm_tails.h"
 #include "asm_filter.h"
+#include "asm_ingest.h"
 
 struct asm_handle {
     int device = 0;
@@ -47,7 +58,74 @@ struct asm_handle {
     unsigned prof_select = 0xfu;          /* which kernels are bracketed: bit 0 pack, 1 NW, 2 LEAP, 3 Greedy */
     uint32_t* d_todo = nullptr;           /* affine NW: [0] = count, [1..] = bucket slots the wavefront band could not settle */
     size_t todo_cap = 0;
+    /* Device memory of batches is recycled instead of freed: a streamed file, or the reference-shaped per-pair objects, create
+     * and drop a batch per call, and hipMalloc / hipFree cost more than the kernels (hipFree also drains the device).  Blocks
+     * are handed out again in stream order (everything a handle enqueues is ordered on its stream), so no wait is needed. */
+    std::unordered_map<void*, size_t> pool_live;
+    std::multimap<size_t, void*> pool_idle;
+    size_t pool_idle_bytes = 0;
+    bool pooling = true;                  /* ASM_POOL=0: plain hipMalloc / hipFree */
+    /* pinned host memory of asm_stream_seq_file, kept between calls (pinning 200 MB costs as much as streaming it) */
+    char* pin_raw[3] = {nullptr, nullptr, nullptr};
+    size_t pin_raw_cap = 0;
+    int32_t* pin_pen[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    int64_t pin_pen_cap[2][3] = {{0, 0, 0}, {0, 0, 0}};
 };
+
+static size_t pool_round(size_t bytes) { /* eight size classes per octave, at least 4 KiB */
+    if (bytes <= 4096) return 4096;
+    int top = 63 - __builtin_clzll((unsigned long long)bytes);
+    const size_t step = (size_t)1 << (top - 3);
+    return (bytes + step - 1) & ~(step - 1);
+}
+
+static void pool_release_idle(asm_handle* h) {
+    for (auto& kv : h->pool_idle) (void)hipFree(kv.second);
+    h->pool_idle.clear();
+    h->pool_idle_bytes = 0;
+}
+
+static hipError_t pool_alloc(asm_handle* h, void** p, size_t bytes) {
+    if (!h->pooling) return hipMalloc(p, bytes ? bytes : 1);
+    const size_t want = pool_round(bytes);
+    auto it = h->pool_idle.lower_bound(want);
+    if (it != h->pool_idle.end() && it->first <= want + want / 4) { /* a block of this class or slightly above */
+        *p = it->second;
+        h->pool_live[*p] = it->first;
+        h->pool_idle_bytes -= it->first;
+        h->pool_idle.erase(it);
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(p, want);
+    if (e != hipSuccess) { /* out of memory: give the idle blocks back and try once more */
+        (void)hipGetLastError();
+        pool_release_idle(h);
+        e = hipMalloc(p, want);
+    }
+    if (e == hipSuccess) h->pool_live[*p] = want;
+    return e;
+}
+
+static void pool_free(asm_handle* h, void* p) {
+    if (!p) return;
+    if (!h || !h->pooling) {
+        (void)hipFree(p);
+        return;
+    }
+    auto it = h->pool_live.find(p);
+    if (it == h->pool_live.end()) { /* not ours (allocated before pooling was switched, or by another handle) */
+        (void)hipFree(p);
+        return;
+    }
+    const size_t sz = it->second;
+    h->pool_live.erase(it);
+    if (h->pool_idle_bytes + sz > ((size_t)24 << 30)) { /* keep at most 24 GiB idle */
+        (void)hipFree(p);
+        return;
+    }
+    h->pool_idle.emplace(sz, p);
+    h->pool_idle_bytes += sz;
+}
 
 /* One width class of a batch: pairs whose longer string needs `w4` granules of 128 positions. */
 struct asm_bucket {
@@ -60,6 +138,7 @@ struct asm_bucket {
 };
 
 struct asm_batch {
+    asm_handle* owner = nullptr; /* whose pool the device blocks come from */
     int64_t n = 0;
     int maxlen = 0;
     int greedy_mode = ASM_GREEDY_CLEAN;
@@ -361,6 +440,7 @@ int asm_create(asm_handle** out, int device) {
     if ((env = getenv("ASM_BUCKET"))) h->bucketing = env[0] != '0';
     if ((env = getenv("ASM_WAVE"))) h->wave_kernels = env[0] != '0';
     if ((env = getenv("ASM_GROUP"))) h->group_kernels = env[0] != '0';
+    if ((env = getenv("ASM_POOL"))) h->pooling = env[0] != '0';
     if ((env = getenv("ASM_PERSIST_WIDE"))) h->persist_wide = env[0] != '0';
     if ((env = getenv("ASM_NW_BANDED"))) h->nw_banded = env[0] != '0';
     if ((env = getenv("ASM_NW_WFA"))) h->nw_wfa = env[0] != '0';
@@ -380,6 +460,14 @@ int asm_destroy(asm_handle* h) {
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->d_todo) (void)hipFree(h->d_todo);
     for (hipEvent_t ev : h->prof_ev) (void)hipEventDestroy(ev);
+    (void)hipDeviceSynchronize();
+    for (char* q : h->pin_raw)
+        if (q) (void)hipHostFree(q);
+    for (auto& row : h->pin_pen)
+        for (int32_t* q : row)
+            if (q) (void)hipHostFree(q);
+    pool_release_idle(h);
+    for (auto& kv : h->pool_live) (void)hipFree(kv.first); /* batches the caller never freed */
     delete h;
     return ASM_OK;
 }
@@ -463,18 +551,18 @@ int asm_generate_pairs(const asm_gen_config* cfg, int64_t first, int64_t n, uint
 
 static void batch_release(asm_batch* b) {
     if (!b) return;
-    (void)hipFree(b->d_reads);
-    (void)hipFree(b->d_refs);
-    (void)hipFree(b->d_read_off);
-    (void)hipFree(b->d_ref_off);
-    (void)hipFree(b->d_planes);
-    (void)hipFree(b->d_lens);
-    (void)hipFree(b->d_order);
-    (void)hipFree(b->d_pos);
-    (void)hipFree(b->d_tails);
-    (void)hipFree(b->d_tail_g0);
-    (void)hipFree(b->d_tail_l0);
-    (void)hipFree(b->d_tail_chunks);
+    pool_free(b->owner, b->d_reads);
+    pool_free(b->owner, b->d_refs);
+    pool_free(b->owner, b->d_read_off);
+    pool_free(b->owner, b->d_ref_off);
+    pool_free(b->owner, b->d_planes);
+    pool_free(b->owner, b->d_lens);
+    pool_free(b->owner, b->d_order);
+    pool_free(b->owner, b->d_pos);
+    pool_free(b->owner, b->d_tails);
+    pool_free(b->owner, b->d_tail_g0);
+    pool_free(b->owner, b->d_tail_l0);
+    pool_free(b->owner, b->d_tail_chunks);
     delete b;
 }
 
@@ -526,11 +614,11 @@ static int batch_resolve_tails(asm_handle* h, asm_batch* b, const uint8_t* init2
     if (init256) memcpy(init.code, init256, 256);
     else memset(init.code, 0, 256);
     /* scratch lives with the batch: a streamed file re-resolves every chunk, a bench step every iteration */
-    if (emit && !b->d_tails) HIPCHK(h, hipMalloc((void**)&b->d_tails, sizeof(uint4) * 4 * (size_t)b->n));
+    if (emit && !b->d_tails) HIPCHK(h, pool_alloc(h, (void**)&b->d_tails, sizeof(uint4) * 4 * (size_t)b->n));
     if (!b->d_tail_g0) {
-        HIPCHK(h, hipMalloc((void**)&b->d_tail_g0, sizeof(uint4) * 4 * (size_t)b->n));
-        HIPCHK(h, hipMalloc((void**)&b->d_tail_l0, sizeof(uint32_t) * (size_t)b->n));
-        HIPCHK(h, hipMalloc((void**)&b->d_tail_chunks, (size_t)nchunks * 512 + 256)); /* last[nchunks][256], carry[nchunks][256], summary[256] */
+        HIPCHK(h, pool_alloc(h, (void**)&b->d_tail_g0, sizeof(uint4) * 4 * (size_t)b->n));
+        HIPCHK(h, pool_alloc(h, (void**)&b->d_tail_l0, sizeof(uint32_t) * (size_t)b->n));
+        HIPCHK(h, pool_alloc(h, (void**)&b->d_tail_chunks, (size_t)nchunks * 512 + 256)); /* last[nchunks][256], carry[nchunks][256], summary[256] */
     }
     uint8_t* const d_last = b->d_tail_chunks;
     uint8_t* const d_carry = d_last + (size_t)nchunks * 256;
@@ -572,10 +660,10 @@ static int batch_finish(asm_handle* h, asm_batch* b) {
     }
         bool bucketed = false;
         if (wmax > 1 && n >= 4096 && h->bucketing) {
-            TRY(hipMalloc((void**)&d_cls, (size_t)n));
-            TRY(hipMalloc((void**)&d_cls2, (size_t)n));
-            TRY(hipMalloc((void**)&d_idx, sizeof(uint32_t) * (size_t)n));
-            TRY(hipMalloc((void**)&d_counts, 16));
+            TRY(pool_alloc(h, (void**)&d_cls, (size_t)n));
+            TRY(pool_alloc(h, (void**)&d_cls2, (size_t)n));
+            TRY(pool_alloc(h, (void**)&d_idx, sizeof(uint32_t) * (size_t)n));
+            TRY(pool_alloc(h, (void**)&d_counts, 16));
             TRY(hipMemsetAsync(d_counts, 0, 16, h->stream));
             hipLaunchKernelGGL(classify_kernel, dim3(grid_for(n)), dim3(ASM_BLOCK), 0, h->stream, b->d_read_off, b->d_ref_off,
                                (long)n, d_cls, d_idx, d_counts);
@@ -586,12 +674,12 @@ static int batch_finish(asm_handle* h, asm_batch* b) {
             for (int c = 0; c < 4; c++) classes += counts[c] ? 1 : 0;
             bucketed = classes > 1;
             if (bucketed) {
-                TRY(hipMalloc((void**)&b->d_order, sizeof(uint32_t) * (size_t)n));
-                TRY(hipMalloc((void**)&b->d_pos, sizeof(uint32_t) * (size_t)n));
+                TRY(pool_alloc(h, (void**)&b->d_order, sizeof(uint32_t) * (size_t)n));
+                TRY(pool_alloc(h, (void**)&b->d_pos, sizeof(uint32_t) * (size_t)n));
                 size_t tmp_bytes = 0;
                 TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_cls, d_cls2, d_idx, b->d_order, (int)n, 0, 2,
                                                        h->stream));
-                TRY(hipMalloc(&d_tmp, tmp_bytes + 16));
+                TRY(pool_alloc(h, &d_tmp, tmp_bytes + 16));
                 TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_cls, d_cls2, d_idx, b->d_order, (int)n, 0, 2,
                                                        h->stream)); /* stable: input order is kept inside a class */
                 hipLaunchKernelGGL(invert_order_kernel, dim3(grid_for(n)), dim3(ASM_BLOCK), 0, h->stream, b->d_order, (long)n,
@@ -623,8 +711,8 @@ static int batch_finish(asm_handle* h, asm_batch* b) {
         }
         b->pb.nb = b->nb;
         b->pb.start[b->nb] = slot;
-        TRY(hipMalloc((void**)&b->d_planes, sizeof(uint4) * (plane_total ? plane_total : 1)));
-        TRY(hipMalloc((void**)&b->d_lens, sizeof(uint32_t) * (size_t)(n > 0 ? n : 1)));
+        TRY(pool_alloc(h, (void**)&b->d_planes, sizeof(uint4) * (plane_total ? plane_total : 1)));
+        TRY(pool_alloc(h, (void**)&b->d_lens, sizeof(uint32_t) * (size_t)(n > 0 ? n : 1)));
         for (int q = 0; q < b->nb; q++) {
             b->bk[q].planes = b->d_planes + b->pb.plane_off[q];
             b->bk[q].lens = b->d_lens + b->pb.start[q];
@@ -637,11 +725,11 @@ static int batch_finish(asm_handle* h, asm_batch* b) {
         if (rc) break;
         if (hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(h, ASM_ENODEVICE, "batch: stream synchronize failed");
     } while (0);
-    (void)hipFree(d_cls);
-    (void)hipFree(d_cls2);
-    (void)hipFree(d_idx);
-    (void)hipFree(d_counts);
-    (void)hipFree(d_tmp);
+    pool_free(h, d_cls);
+    pool_free(h, d_cls2);
+    pool_free(h, d_idx);
+    pool_free(h, d_counts);
+    pool_free(h, d_tmp);
     return rc;
 }
 
@@ -664,6 +752,7 @@ int asm_batch_upload(asm_handle* h, int64_t n, const char* reads, const uint32_t
     if (maxlen > ASM_MAX_LENGTH)
         return fail(h, ASM_EUNSUPPORTED, "asm_batch_upload: a sequence is longer than ASM_MAX_LENGTH");
     asm_batch* b = new asm_batch;
+    b->owner = h;
     b->n = n;
     b->maxlen = maxlen;
     b->greedy_mode = greedy_mode;
@@ -676,10 +765,10 @@ int asm_batch_upload(asm_handle* h, int64_t n, const char* reads, const uint32_t
         rc = fail(h, ASM_ENOMEM, std::string(#call) + " failed"); \
         break;                                             \
     }
-        TRY(hipMalloc((void**)&b->d_reads, b->reads_bytes + 16));
-        TRY(hipMalloc((void**)&b->d_refs, b->refs_bytes + 16));
-        TRY(hipMalloc((void**)&b->d_read_off, sizeof(uint32_t) * (size_t)(n + 1)));
-        TRY(hipMalloc((void**)&b->d_ref_off, sizeof(uint32_t) * (size_t)(n + 1)));
+        TRY(pool_alloc(h, (void**)&b->d_reads, b->reads_bytes + 16));
+        TRY(pool_alloc(h, (void**)&b->d_refs, b->refs_bytes + 16));
+        TRY(pool_alloc(h, (void**)&b->d_read_off, sizeof(uint32_t) * (size_t)(n + 1)));
+        TRY(pool_alloc(h, (void**)&b->d_ref_off, sizeof(uint32_t) * (size_t)(n + 1)));
         TRY(hipMemcpyAsync(b->d_reads, reads, b->reads_bytes, hipMemcpyHostToDevice, h->stream));
         TRY(hipMemcpyAsync(b->d_refs, refs, b->refs_bytes, hipMemcpyHostToDevice, h->stream));
         TRY(hipMemcpyAsync(b->d_read_off, read_off, sizeof(uint32_t) * (size_t)(n + 1), hipMemcpyHostToDevice, h->stream));
@@ -705,6 +794,7 @@ int asm_batch_generate(asm_handle* h, const asm_gen_config* cfg, int64_t first, 
     *out = nullptr;
     HIPCHK(h, hipSetDevice(h->device));
     asm_batch* b = new asm_batch;
+    b->owner = h;
     b->n = n;
     b->greedy_mode = greedy_mode;
     uint32_t *d_m = nullptr, *d_n = nullptr, *d_max = nullptr;
@@ -717,11 +807,11 @@ int asm_batch_generate(asm_handle* h, const asm_gen_config* cfg, int64_t first, 
         break;                                                     \
     }
         const size_t cnt = (size_t)n + 1;
-        TRY(hipMalloc((void**)&d_m, sizeof(uint32_t) * cnt));
-        TRY(hipMalloc((void**)&d_n, sizeof(uint32_t) * cnt));
-        TRY(hipMalloc((void**)&d_max, sizeof(uint32_t) * 2));
-        TRY(hipMalloc((void**)&b->d_read_off, sizeof(uint32_t) * cnt));
-        TRY(hipMalloc((void**)&b->d_ref_off, sizeof(uint32_t) * cnt));
+        TRY(pool_alloc(h, (void**)&d_m, sizeof(uint32_t) * cnt));
+        TRY(pool_alloc(h, (void**)&d_n, sizeof(uint32_t) * cnt));
+        TRY(pool_alloc(h, (void**)&d_max, sizeof(uint32_t) * 2));
+        TRY(pool_alloc(h, (void**)&b->d_read_off, sizeof(uint32_t) * cnt));
+        TRY(pool_alloc(h, (void**)&b->d_ref_off, sizeof(uint32_t) * cnt));
         TRY(hipMemsetAsync(d_m, 0, sizeof(uint32_t) * cnt, h->stream));
         TRY(hipMemsetAsync(d_n, 0, sizeof(uint32_t) * cnt, h->stream));
         if (n > 0) {
@@ -733,7 +823,7 @@ int asm_batch_generate(asm_handle* h, const asm_gen_config* cfg, int64_t first, 
         TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_m, b->d_read_off, (int)cnt, h->stream));
         TRY(hipcub::DeviceReduce::Max(nullptr, t2, d_n, d_max, (int)cnt, h->stream));
         if (t2 > tmp_bytes) tmp_bytes = t2;
-        TRY(hipMalloc(&d_tmp, tmp_bytes + 16));
+        TRY(pool_alloc(h, &d_tmp, tmp_bytes + 16));
         TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_m, b->d_read_off, (int)cnt, h->stream));
         TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_n, b->d_ref_off, (int)cnt, h->stream));
         TRY(hipcub::DeviceReduce::Max(d_tmp, tmp_bytes, d_m, d_max, (int)cnt, h->stream));
@@ -758,8 +848,8 @@ int asm_batch_generate(asm_handle* h, const asm_gen_config* cfg, int64_t first, 
             rc = fail(h, ASM_EUNSUPPORTED, "asm_batch_generate: a generated sequence exceeds ASM_MAX_LENGTH");
             break;
         }
-        TRY(hipMalloc((void**)&b->d_reads, b->reads_bytes + 16));
-        TRY(hipMalloc((void**)&b->d_refs, b->refs_bytes + 16));
+        TRY(pool_alloc(h, (void**)&b->d_reads, b->reads_bytes + 16));
+        TRY(pool_alloc(h, (void**)&b->d_refs, b->refs_bytes + 16));
         if (n > 0) {
             hipLaunchKernelGGL(gen_fill_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, *cfg, (long)first,
                                (long)n, b->d_read_off, b->d_ref_off, b->d_reads, b->d_refs);
@@ -768,10 +858,10 @@ int asm_batch_generate(asm_handle* h, const asm_gen_config* cfg, int64_t first, 
 #undef TRY
         rc = batch_finish(h, b);
     } while (0);
-    (void)hipFree(d_m);
-    (void)hipFree(d_n);
-    (void)hipFree(d_max);
-    (void)hipFree(d_tmp);
+    pool_free(h, d_m);
+    pool_free(h, d_n);
+    pool_free(h, d_max);
+    pool_free(h, d_tmp);
     if (rc) {
         batch_release(b);
         return rc;
@@ -824,6 +914,7 @@ int asm_batch_from_hits(asm_handle* h, const asm_reference* ref, int64_t n, cons
     }
     if (maxlen + 1 > ASM_MAX_LENGTH) return fail(h, ASM_EUNSUPPORTED, "asm_batch_from_hits: a read is longer than ASM_MAX_LENGTH - 1");
     asm_batch* b = new asm_batch;
+    b->owner = h;
     b->n = n;
     b->maxlen = maxlen + 1; /* the window is one base longer than the read (mapper/main.cpp:80) */
     b->greedy_mode = greedy_mode;
@@ -839,11 +930,11 @@ int asm_batch_from_hits(asm_handle* h, const asm_reference* ref, int64_t n, cons
         break;                                                           \
     }
         const size_t cnt = (size_t)n + 1;
-        TRY(hipMalloc((void**)&b->d_reads, b->reads_bytes + 16));
-        TRY(hipMalloc((void**)&b->d_read_off, sizeof(uint32_t) * cnt));
-        TRY(hipMalloc((void**)&b->d_ref_off, sizeof(uint32_t) * cnt));
-        TRY(hipMalloc((void**)&d_pos, sizeof(unsigned long long) * cnt));
-        TRY(hipMalloc((void**)&d_wl, sizeof(uint32_t) * cnt));
+        TRY(pool_alloc(h, (void**)&b->d_reads, b->reads_bytes + 16));
+        TRY(pool_alloc(h, (void**)&b->d_read_off, sizeof(uint32_t) * cnt));
+        TRY(pool_alloc(h, (void**)&b->d_ref_off, sizeof(uint32_t) * cnt));
+        TRY(pool_alloc(h, (void**)&d_pos, sizeof(unsigned long long) * cnt));
+        TRY(pool_alloc(h, (void**)&d_wl, sizeof(uint32_t) * cnt));
         TRY(hipMemcpyAsync(b->d_reads, reads, b->reads_bytes, hipMemcpyHostToDevice, h->stream));
         TRY(hipMemcpyAsync(b->d_read_off, read_off, sizeof(uint32_t) * cnt, hipMemcpyHostToDevice, h->stream));
         if (n) TRY(hipMemcpyAsync(d_pos, hit_pos, sizeof(unsigned long long) * (size_t)n, hipMemcpyHostToDevice, h->stream));
@@ -852,13 +943,13 @@ int asm_batch_from_hits(asm_handle* h, const asm_reference* ref, int64_t n, cons
         TRY(hipGetLastError());
         size_t tmp_bytes = 0;
         TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_wl, b->d_ref_off, (int)cnt, h->stream));
-        TRY(hipMalloc(&d_tmp, tmp_bytes + 16));
+        TRY(pool_alloc(h, &d_tmp, tmp_bytes + 16));
         TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_wl, b->d_ref_off, (int)cnt, h->stream));
         uint32_t total = 0;
         TRY(hipMemcpyAsync(&total, b->d_ref_off + n, 4, hipMemcpyDeviceToHost, h->stream));
         TRY(hipStreamSynchronize(h->stream));
         b->refs_bytes = total;
-        TRY(hipMalloc((void**)&b->d_refs, b->refs_bytes + 16));
+        TRY(pool_alloc(h, (void**)&b->d_refs, b->refs_bytes + 16));
         if (n) {
             int64_t blocks = (n + 3) / 4;
             blocks = blocks > 256 * 16 ? 256 * 16 : blocks;
@@ -869,9 +960,9 @@ int asm_batch_from_hits(asm_handle* h, const asm_reference* ref, int64_t n, cons
 #undef TRY
         rc = batch_finish(h, b);
     } while (0);
-    (void)hipFree(d_pos);
-    (void)hipFree(d_wl);
-    (void)hipFree(d_tmp);
+    pool_free(h, d_pos);
+    pool_free(h, d_wl);
+    pool_free(h, d_tmp);
     if (rc) {
         batch_release(b);
         return rc;
@@ -1217,7 +1308,7 @@ int asm_align_batch(asm_handle* h, int aligner, int64_t n, const char* reads, co
     rc = asm_batch_upload(h, n, reads, read_off, refs, ref_off, greedy_mode, &b);
     if (rc) return rc;
     int32_t* d_out = nullptr;
-    if (hipMalloc((void**)&d_out, sizeof(int32_t) * (size_t)(n > 0 ? n : 1)) != hipSuccess) {
+    if (pool_alloc(h, (void**)&d_out, sizeof(int32_t) * (size_t)(n > 0 ? n : 1)) != hipSuccess) {
         batch_release(b);
         return fail(h, ASM_ENOMEM, "asm_align_batch: hipMalloc failed");
     }
@@ -1225,7 +1316,7 @@ int asm_align_batch(asm_handle* h, int aligner, int64_t n, const char* reads, co
     if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(h, ASM_ENODEVICE, "asm_align_batch: kernel failed");
     if (!rc && n > 0 && hipMemcpy(penalties, d_out, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
         rc = fail(h, ASM_ENODEVICE, "asm_align_batch: copy back failed");
-    (void)hipFree(d_out);
+    pool_free(h, d_out);
     batch_release(b);
     return rc;
 }
@@ -1438,16 +1529,477 @@ int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, in
 }
 
 /* ---------------------------------------------------------------------------------------------------- */
+/* Streaming ingest: a `>read\n<ref\n` file (benchmark_utils.h:325-352) through the aligners in chunks.
+ *   reader threads   pread() the next chunk into pinned host memory (three buffers in rotation) and count its newlines, so
+ *                    that the chunk ends on a pair boundary; what follows the boundary is carried into the next chunk
+ *   copy stream      raw bytes -> HBM (two device buffers), overlapped with the compute stream's work on the chunk before
+ *   compute stream   parse on the device (asm_ingest.h), pack, [sequential mode: chain the stale tails from the state the
+ *                    chunks before left behind], NW / LEAP / Greedy, counters, penalties back into pinned staging
+ *   caller's thread  hands results of chunk c-2 to the caller's arrays while chunk c-1 computes and chunk c is copied */
+namespace {
+
+struct SeqSlot { /* one pinned host buffer */
+    char* buf = nullptr;
+    size_t cap = 0;
+    size_t bytes = 0;     /* raw bytes to ship: whole pairs only */
+    int64_t pairs = 0;
+    bool last = false;
+    bool ready = false;   /* filled by the reader, not yet shipped */
+    bool in_flight = false; /* an H2D copy out of it has been enqueued; ev_shipped tells when it is over */
+    hipEvent_t ev_shipped = nullptr;
+};
+
+/* newlines in [p, p+len): count and the positions (relative to p) of the last two */
+struct NlScan {
+    int64_t count = 0;
+    int64_t last = -1, prev = -1;
+};
+static NlScan scan_newlines(const char* p, size_t len, int threads) {
+    if (threads < 1) threads = 1;
+    std::vector<NlScan> part((size_t)threads);
+    std::vector<std::thread> pool;
+    const size_t step = (len + (size_t)threads - 1) / (size_t)threads;
+    auto work = [&](int t) {
+        const size_t a = (size_t)t * step, b = a + step < len ? a + step : len;
+        NlScan r;
+        const char* q = p + a;
+        const char* end = p + (a < b ? b : a);
+        while (q < end) {
+            const char* hit = (const char*)memchr(q, '\n', (size_t)(end - q));
+            if (!hit) break;
+            r.count++, r.prev = r.last, r.last = (int64_t)(hit - p);
+            q = hit + 1;
+        }
+        part[(size_t)t] = r;
+    };
+    for (int t = 1; t < threads; t++) pool.emplace_back(work, t);
+    work(0);
+    for (auto& th : pool) th.join();
+    NlScan tot;
+    for (const NlScan& r : part) {
+        if (!r.count) continue;
+        tot.count += r.count;
+        if (r.count >= 2) tot.prev = r.prev;
+        else tot.prev = tot.last; /* the segment's only newline: the one before it is the running last */
+        tot.last = r.last;
+    }
+    return tot;
+}
+
+static void parallel_pread(int fd, char* dst, size_t len, off_t off, int threads, std::atomic<bool>& failed) {
+    if (threads < 1) threads = 1;
+    std::vector<std::thread> pool;
+    const size_t step = ((len + (size_t)threads - 1) / (size_t)threads + 4095) & ~(size_t)4095;
+    auto work = [&](int t) {
+        size_t a = (size_t)t * step;
+        const size_t b = a + step < len ? a + step : len;
+        while (a < b) {
+            const ssize_t got = pread(fd, dst + a, b - a, off + (off_t)a);
+            if (got <= 0) {
+                failed = true;
+                return;
+            }
+            a += (size_t)got;
+        }
+    };
+    for (int t = 1; t < threads; t++) pool.emplace_back(work, t);
+    work(0);
+    for (auto& th : pool) th.join();
+}
+
+/* A batch out of raw text already in HBM (n pairs = 2n lines, every line ending in '\n'). */
+static int batch_from_device_text(asm_handle* h, const char* d_raw, size_t nbytes, int64_t n, int greedy_mode, asm_batch** out) {
+    *out = nullptr;
+    asm_batch* b = new asm_batch;
+    b->owner = h;
+    b->n = n;
+    b->greedy_mode = greedy_mode;
+    uint32_t *d_tile = nullptr, *d_tbase = nullptr, *d_nl = nullptr, *d_m = nullptr, *d_n = nullptr, *d_max = nullptr;
+    unsigned long long *d_sa = nullptr, *d_sb = nullptr;
+    void* d_tmp = nullptr;
+    int rc = ASM_OK;
+    do {
+#define TRY(call)                                                        \
+    if ((call) != hipSuccess) {                                          \
+        rc = fail(h, ASM_ENODEVICE, std::string(#call) + " failed");     \
+        break;                                                           \
+    }
+        const size_t cnt = (size_t)n + 1;
+        const long ntiles = (long)((nbytes + SEQ_TILE - 1) / SEQ_TILE);
+        TRY(pool_alloc(h, (void**)&b->d_read_off, sizeof(uint32_t) * cnt));
+        TRY(pool_alloc(h, (void**)&b->d_ref_off, sizeof(uint32_t) * cnt));
+        TRY(pool_alloc(h, (void**)&d_m, sizeof(uint32_t) * cnt));
+        TRY(pool_alloc(h, (void**)&d_n, sizeof(uint32_t) * cnt));
+        TRY(pool_alloc(h, (void**)&d_sa, sizeof(unsigned long long) * cnt));
+        TRY(pool_alloc(h, (void**)&d_sb, sizeof(unsigned long long) * cnt));
+        TRY(pool_alloc(h, (void**)&d_nl, sizeof(uint32_t) * (2 * (size_t)n + 2)));
+        TRY(pool_alloc(h, (void**)&d_tile, sizeof(uint32_t) * ((size_t)ntiles + 1)));
+        TRY(pool_alloc(h, (void**)&d_tbase, sizeof(uint32_t) * ((size_t)ntiles + 1)));
+        TRY(pool_alloc(h, (void**)&d_max, 16));
+        TRY(hipMemsetAsync(d_max, 0, 16, h->stream));
+        size_t tmp_bytes = 0, t2 = 0;
+        TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_tile, d_tbase, (int)ntiles, h->stream));
+        TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, t2, d_m, b->d_read_off, (int)cnt, h->stream));
+        tmp_bytes = t2 > tmp_bytes ? t2 : tmp_bytes;
+        TRY(pool_alloc(h, &d_tmp, tmp_bytes + 16));
+        if (n > 0) {
+            hipLaunchKernelGGL(seq_count_kernel, dim3((unsigned)ntiles), dim3(256), 0, h->stream, d_raw, (long)nbytes, d_tile);
+            TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_tile, d_tbase, (int)ntiles, h->stream));
+            hipLaunchKernelGGL(seq_index_kernel, dim3((unsigned)ntiles), dim3(256), 0, h->stream, d_raw, (long)nbytes,
+                               (const uint32_t*)d_tbase, d_nl, (long)(2 * n));
+        }
+        hipLaunchKernelGGL(seq_lengths_kernel, dim3(grid_for(n + 1)), dim3(ASM_BLOCK), 0, h->stream, (const uint32_t*)d_nl, (long)n,
+                           d_m, d_n, d_sa, d_sb);
+        TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_m, b->d_read_off, (int)cnt, h->stream));
+        TRY(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_n, b->d_ref_off, (int)cnt, h->stream));
+        if (n > 0) {
+            int64_t blocks = (n + ASM_BLOCK - 1) / ASM_BLOCK;
+            blocks = blocks > 1024 ? 1024 : blocks;
+            hipLaunchKernelGGL(seq_max_kernel, dim3((unsigned)blocks), dim3(ASM_BLOCK), 0, h->stream, (const uint32_t*)d_m,
+                               (const uint32_t*)d_n, (long)n, d_max);
+        }
+        TRY(hipGetLastError());
+        uint32_t tot[2] = {0, 0}, mx = 0;
+        TRY(hipMemcpyAsync(&tot[0], b->d_read_off + n, 4, hipMemcpyDeviceToHost, h->stream));
+        TRY(hipMemcpyAsync(&tot[1], b->d_ref_off + n, 4, hipMemcpyDeviceToHost, h->stream));
+        TRY(hipMemcpyAsync(&mx, d_max, 4, hipMemcpyDeviceToHost, h->stream));
+        TRY(hipStreamSynchronize(h->stream));
+        if ((int)mx > ASM_MAX_LENGTH) {
+            rc = fail(h, ASM_EUNSUPPORTED, "streamed file: a sequence is longer than ASM_MAX_LENGTH");
+            break;
+        }
+        b->reads_bytes = tot[0], b->refs_bytes = tot[1], b->maxlen = (int)mx;
+        TRY(pool_alloc(h, (void**)&b->d_reads, b->reads_bytes + 16));
+        TRY(pool_alloc(h, (void**)&b->d_refs, b->refs_bytes + 16));
+        if (n > 0) {
+            int64_t blocks = (n + 3) / 4;
+            blocks = blocks > 256 * 16 ? 256 * 16 : blocks;
+            hipLaunchKernelGGL(seq_gather_kernel, dim3((unsigned)blocks), dim3(ASM_BLOCK), 0, h->stream, d_raw,
+                               (const unsigned long long*)d_sa, (const uint32_t*)b->d_read_off, (long)n, b->d_reads);
+            hipLaunchKernelGGL(seq_gather_kernel, dim3((unsigned)blocks), dim3(ASM_BLOCK), 0, h->stream, d_raw,
+                               (const unsigned long long*)d_sb, (const uint32_t*)b->d_ref_off, (long)n, b->d_refs);
+            TRY(hipGetLastError());
+        }
+#undef TRY
+        rc = batch_finish(h, b);
+    } while (0);
+    pool_free(h, d_tile), pool_free(h, d_tbase), pool_free(h, d_nl), pool_free(h, d_m), pool_free(h, d_n);
+    pool_free(h, d_sa), pool_free(h, d_sb), pool_free(h, d_max), pool_free(h, d_tmp);
+    if (rc) {
+        batch_release(b);
+        return rc;
+    }
+    *out = b;
+    return ASM_OK;
+}
+
+}  // namespace
+
+int asm_batch_from_text(asm_handle* h, const char* text, size_t nbytes, int greedy_mode, asm_batch** out) {
+    if (!h || !out || (!text && nbytes)) return fail(h, ASM_EINVAL, "asm_batch_from_text: bad argument");
+    if (greedy_mode != ASM_GREEDY_CLEAN && greedy_mode != ASM_GREEDY_SEQUENTIAL)
+        return fail(h, ASM_EINVAL, "asm_batch_from_text: unknown greedy_mode");
+    if (nbytes >= 0xfffffff0ull) return fail(h, ASM_EUNSUPPORTED, "asm_batch_from_text: more than 4 GiB of text; split it");
+    HIPCHK(h, hipSetDevice(h->device));
+    const bool open_line = nbytes && text[nbytes - 1] != '\n';
+    NlScan sc = scan_newlines(text, nbytes, 8);
+    int64_t lines = sc.count + (open_line ? 1 : 0);
+    const bool odd = (lines & 1) != 0; /* a read without its reference line: the reference gets an empty string there */
+    const size_t total = nbytes + (open_line ? 1 : 0) + (odd ? 1 : 0);
+    lines += odd ? 1 : 0;
+    char* d_raw = nullptr;
+    HIPCHK(h, pool_alloc(h, (void**)&d_raw, total + 32));
+    int rc = ASM_OK;
+    if (nbytes && hipMemcpyAsync(d_raw, text, nbytes, hipMemcpyHostToDevice, h->stream) != hipSuccess) rc = fail(h, ASM_ENODEVICE, "asm_batch_from_text: copy failed");
+    if (!rc && total > nbytes && hipMemsetAsync(d_raw + nbytes, '\n', total - nbytes, h->stream) != hipSuccess) rc = fail(h, ASM_ENODEVICE, "asm_batch_from_text: memset failed");
+    if (!rc) rc = batch_from_device_text(h, d_raw, total, lines / 2, greedy_mode, out);
+    pool_free(h, d_raw);
+    return rc;
+}
+
+int asm_stream_seq_file(asm_handle* h, const char* path, const asm_params* p, int greedy_mode, int aligner_mask,
+                        int64_t chunk_bytes, int64_t max_pairs, int32_t* nw, int32_t* leap, int32_t* greedy, int64_t out_cap,
+                        const int32_t* answers, int64_t n_answers, asm_stream_stats* stats) {
+    if (!h || !path || !p || !stats) return fail(h, ASM_EINVAL, "asm_stream_seq_file: NULL argument");
+    if (greedy_mode != ASM_GREEDY_CLEAN && greedy_mode != ASM_GREEDY_SEQUENTIAL)
+        return fail(h, ASM_EINVAL, "asm_stream_seq_file: unknown greedy_mode");
+    memset(stats, 0, sizeof *stats);
+    const bool do_nw = (aligner_mask & 1) != 0, do_leap = (aligner_mask & 2) != 0, do_greedy = (aligner_mask & 4) != 0;
+    if (!(do_nw || do_leap || do_greedy)) return fail(h, ASM_EINVAL, "asm_stream_seq_file: empty aligner mask");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(h, ASM_EINVAL, std::string("asm_stream_seq_file: cannot open ") + path); /* benchmark_utils.h:350 */
+    struct stat st;
+    if (fstat(fd, &st) != 0) {
+        close(fd);
+        return fail(h, ASM_EINVAL, "asm_stream_seq_file: fstat failed");
+    }
+    const size_t file_bytes = (size_t)st.st_size;
+    size_t chunk = chunk_bytes > 0 ? (size_t)chunk_bytes : ((size_t)64 << 20);
+    chunk = chunk < 4096 ? 4096 : chunk;
+    if (chunk > ((size_t)1 << 30)) chunk = (size_t)1 << 30;
+    const size_t slot_cap = chunk + ((size_t)4 << 20); /* + room for the carried tail and the EOF padding */
+    const int reader_threads = 8;
+    const auto t_begin = std::chrono::steady_clock::now();
+
+    SeqSlot slot[3];
+    char* d_raw[2] = {nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    int32_t* h_pen[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    int32_t* d_pen[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    int32_t* d_ans[2] = {nullptr, nullptr};
+    unsigned long long* d_cnt = nullptr;
+    int64_t pen_cap = 0;
+    int rc = ASM_OK;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<bool> failed(false), stop(false);
+    double read_seconds = 0;
+    std::thread reader;
+
+    auto cleanup = [&]() {
+        stop = true;
+        cv.notify_all();
+        if (reader.joinable()) reader.join();
+        (void)hipDeviceSynchronize();
+        for (auto& s : slot)
+            if (s.ev_shipped) (void)hipEventDestroy(s.ev_shipped);
+        for (int q = 0; q < 2; q++) {
+            pool_free(h, d_raw[q]);
+            if (ev_h2d[q]) (void)hipEventDestroy(ev_h2d[q]);
+            if (ev_done[q]) (void)hipEventDestroy(ev_done[q]);
+            for (int a = 0; a < 3; a++) pool_free(h, d_pen[q][a]);
+            pool_free(h, d_ans[q]);
+        }
+        pool_free(h, d_cnt);
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        close(fd);
+    };
+#define STREAM_TRY(call)                                                                   \
+    if (!rc && (call) != hipSuccess) rc = fail(h, ASM_ENODEVICE, std::string(#call) + " failed")
+
+    if (h->pin_raw_cap < slot_cap) { /* (re)pin */
+        for (char*& q : h->pin_raw) {
+            if (q) (void)hipHostFree(q);
+            q = nullptr;
+        }
+        h->pin_raw_cap = 0;
+        for (char*& q : h->pin_raw) STREAM_TRY(hipHostMalloc((void**)&q, slot_cap + 64, hipHostMallocDefault));
+        if (!rc) h->pin_raw_cap = slot_cap;
+    }
+    for (int q = 0; q < 3; q++) {
+        slot[q].buf = h->pin_raw[q];
+        slot[q].cap = slot_cap;
+        STREAM_TRY(hipEventCreateWithFlags(&slot[q].ev_shipped, hipEventDisableTiming));
+    }
+    for (int qq = 0; qq < 2; qq++)
+        for (int a = 0; a < 3; a++) h_pen[qq][a] = h->pin_pen[qq][a];
+    pen_cap = 0; /* device staging is (re)allocated with the first chunk; the pinned side is reused when large enough */
+    STREAM_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    for (int q = 0; q < 2; q++) {
+        STREAM_TRY(pool_alloc(h, (void**)&d_raw[q], slot_cap + 64));
+        STREAM_TRY(hipEventCreateWithFlags(&ev_h2d[q], hipEventDisableTiming));
+        STREAM_TRY(hipEventCreateWithFlags(&ev_done[q], hipEventDisableTiming));
+    }
+    STREAM_TRY(pool_alloc(h, (void**)&d_cnt, 32));
+    STREAM_TRY(hipMemsetAsync(d_cnt, 0, 32, h->stream));
+    if (rc) {
+        cleanup();
+        return rc;
+    }
+
+    /* ---- reader: fills slots in rotation ---- */
+    reader = std::thread([&]() {
+        (void)hipSetDevice(h->device);
+        std::vector<char> carry;
+        size_t file_off = 0;
+        int64_t pairs_left = max_pairs > 0 ? max_pairs : INT64_MAX;
+        bool eof = false;
+        for (int c = 0; !eof && !stop; c++) {
+            SeqSlot& s = slot[c % 3];
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || !s.ready; });
+                if (stop) return;
+            }
+            if (s.in_flight) { /* the copy out of this buffer (three chunks ago) must be over before it is overwritten */
+                (void)hipEventSynchronize(s.ev_shipped);
+                s.in_flight = false;
+            }
+            const auto t0 = std::chrono::steady_clock::now();
+            size_t have = carry.size();
+            if (have) memcpy(s.buf, carry.data(), have);
+            carry.clear();
+            size_t want = chunk;
+            if (file_off + want > file_bytes) want = file_bytes - file_off;
+            if (have + want > s.cap - 8) want = s.cap - 8 - have;
+            if (want) parallel_pread(fd, s.buf + have, want, (off_t)file_off, reader_threads, failed);
+            file_off += want;
+            have += want;
+            eof = file_off >= file_bytes;
+            if (eof && have && s.buf[have - 1] != '\n') s.buf[have++] = '\n';
+            NlScan sc = scan_newlines(s.buf, have, reader_threads);
+            if (eof && (sc.count & 1)) { /* a read line without its reference line: an empty reference */
+                s.buf[have++] = '\n';
+                sc.prev = sc.last, sc.last = (int64_t)have - 1, sc.count++;
+            }
+            int64_t lines = sc.count & ~(int64_t)1;
+            size_t boundary = lines == 0 ? 0 : (size_t)((lines == sc.count ? sc.last : sc.prev) + 1);
+            if (lines / 2 > pairs_left) { /* max_pairs cuts inside this chunk: find the boundary of the pairs_left-th pair */
+                const int64_t need = 2 * pairs_left;
+                const char* q = s.buf;
+                for (int64_t l = 0; l < need; l++) q = (const char*)memchr(q, '\n', (size_t)(s.buf + have - q)) + 1;
+                boundary = (size_t)(q - s.buf), lines = need;
+                eof = true;
+            }
+            if (!eof) {
+                if (boundary == 0 && have >= s.cap - 8) failed = true; /* one pair longer than a whole chunk */
+                carry.assign(s.buf + boundary, s.buf + have);
+            }
+            pairs_left -= lines / 2;
+            if (pairs_left <= 0) eof = true;
+            read_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                s.bytes = boundary, s.pairs = lines / 2, s.last = eof, s.ready = true;
+            }
+            cv.notify_all();
+            if (failed) return;
+        }
+    });
+
+    /* ---- caller's thread: ship, compute, harvest ---- */
+    uint8_t tail_state[256];
+    memset(tail_state, 0, sizeof tail_state);
+    int64_t chunk_first[2] = {0, 0}, chunk_pairs[2] = {0, 0};
+    asm_batch* chunk_batch[2] = {nullptr, nullptr};
+    int64_t done_pairs = 0;
+    int maxlen = 0;
+    auto harvest = [&](int q) { /* results of the chunk that used device buffer q */
+        if (chunk_pairs[q] <= 0 && !chunk_batch[q]) return;
+        if (hipEventSynchronize(ev_done[q]) != hipSuccess && !rc) rc = fail(h, ASM_ENODEVICE, "asm_stream_seq_file: chunk failed");
+        int32_t* dst[3] = {nw, leap, greedy};
+        for (int a = 0; a < 3; a++) {
+            if (!dst[a] || !h_pen[q][a]) continue;
+            const int64_t room = out_cap - chunk_first[q];
+            const int64_t cnt = chunk_pairs[q] < room ? chunk_pairs[q] : (room > 0 ? room : 0);
+            if (cnt > 0) memcpy(dst[a] + chunk_first[q], h_pen[q][a], sizeof(int32_t) * (size_t)cnt);
+        }
+        if (chunk_batch[q]) batch_release(chunk_batch[q]);
+        chunk_batch[q] = nullptr;
+        chunk_pairs[q] = 0;
+    };
+    bool last = false;
+    int64_t chunks = 0;
+    size_t bytes_total = 0;
+    for (int c = 0; !last && !rc; c++) {
+        SeqSlot& s = slot[c % 3];
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return s.ready || failed.load(); });
+        }
+        if (failed) {
+            rc = fail(h, ASM_EINVAL, "asm_stream_seq_file: read failed (or one pair is longer than a chunk)");
+            break;
+        }
+        const int q = c & 1;
+        harvest(q); /* chunk c-2 used the same device buffer and staging */
+        last = s.last;
+        const int64_t n = s.pairs;
+        if (n > 0) {
+            if (n > pen_cap || !d_pen[0][0]) { /* staging sized by the largest chunk so far (chunks hold about the same number of pairs) */
+                harvest(q ^ 1);
+                const int64_t cap = n + n / 8 + 1024;
+                for (int qq = 0; qq < 2 && !rc; qq++)
+                    for (int a = 0; a < 3 && !rc; a++) {
+                        if (!((aligner_mask >> a) & 1)) continue;
+                        pool_free(h, d_pen[qq][a]);
+                        d_pen[qq][a] = nullptr;
+                        if (!h->pin_pen[qq][a] || h->pin_pen_cap[qq][a] < cap) {
+                            if (h->pin_pen[qq][a]) (void)hipHostFree(h->pin_pen[qq][a]);
+                            h->pin_pen[qq][a] = nullptr, h->pin_pen_cap[qq][a] = 0;
+                            STREAM_TRY(hipHostMalloc((void**)&h->pin_pen[qq][a], sizeof(int32_t) * (size_t)cap, hipHostMallocDefault));
+                            if (!rc) h->pin_pen_cap[qq][a] = cap;
+                        }
+                        h_pen[qq][a] = h->pin_pen[qq][a];
+                        STREAM_TRY(pool_alloc(h, (void**)&d_pen[qq][a], sizeof(int32_t) * (size_t)cap));
+                    }
+                for (int qq = 0; qq < 2 && !rc && answers; qq++) {
+                    pool_free(h, d_ans[qq]);
+                    d_ans[qq] = nullptr;
+                    STREAM_TRY(pool_alloc(h, (void**)&d_ans[qq], sizeof(int32_t) * (size_t)cap));
+                }
+                pen_cap = cap;
+            }
+            STREAM_TRY(hipMemcpyAsync(d_raw[q], s.buf, s.bytes, hipMemcpyHostToDevice, copy_stream));
+            STREAM_TRY(hipEventRecord(s.ev_shipped, copy_stream));
+            s.in_flight = true;
+            STREAM_TRY(hipEventRecord(ev_h2d[q], copy_stream));
+            STREAM_TRY(hipStreamWaitEvent(h->stream, ev_h2d[q], 0));
+        }
+        const size_t shipped = s.bytes;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            s.ready = false; /* the reader may refill it once ev_shipped has fired */
+        }
+        cv.notify_all();
+        if (n <= 0 || rc) continue;
+        asm_batch* b = nullptr;
+        rc = batch_from_device_text(h, d_raw[q], shipped, n, ASM_GREEDY_CLEAN, &b);
+        if (rc) break;
+        if (greedy_mode == ASM_GREEDY_SEQUENTIAL && do_greedy) { /* the chain of hurdle_matrix.h:136-137 across chunk boundaries */
+            uint8_t summary[256];
+            rc = batch_resolve_tails(h, b, nullptr, summary, false);
+            if (!rc) {
+                b->greedy_mode = ASM_GREEDY_SEQUENTIAL;
+                rc = batch_resolve_tails(h, b, tail_state, nullptr, true);
+            }
+            if (!rc) rc = asm_batch_pack_async(h, b);
+            if (!rc) rc = asm_tail_state_advance(tail_state, summary, n);
+        }
+        const int32_t* ans = nullptr;
+        if (!rc && answers && done_pairs < n_answers) { /* read_answer_file (benchmark_utils.h:358-368): one integer per pair */
+            const int64_t have = n_answers - done_pairs < n ? n_answers - done_pairs : n;
+            std::vector<int32_t> pad((size_t)n, INT32_MIN);
+            memcpy(pad.data(), answers + done_pairs, sizeof(int32_t) * (size_t)have);
+            STREAM_TRY(hipMemcpyAsync(d_ans[q], pad.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+            STREAM_TRY(hipStreamSynchronize(h->stream)); /* `pad` is pageable and about to go out of scope */
+            ans = d_ans[q];
+        }
+        if (!rc)
+            rc = asm_run_benchmark_async(h, b, p, 0, do_nw ? d_pen[q][0] : nullptr, do_leap ? d_pen[q][1] : nullptr,
+                                         do_greedy ? d_pen[q][2] : nullptr, ans, do_nw ? d_cnt : nullptr);
+        for (int a = 0; a < 3 && !rc; a++)
+            if (d_pen[q][a]) STREAM_TRY(hipMemcpyAsync(h_pen[q][a], d_pen[q][a], sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+        STREAM_TRY(hipEventRecord(ev_done[q], h->stream));
+        chunk_batch[q] = b, chunk_first[q] = done_pairs, chunk_pairs[q] = n;
+        maxlen = b->maxlen > maxlen ? b->maxlen : maxlen;
+        done_pairs += n, bytes_total += shipped, chunks++;
+    }
+    harvest(0), harvest(1);
+    if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(h, ASM_ENODEVICE, "asm_stream_seq_file: stream synchronize failed");
+    if (!rc && hipMemcpy(stats->counters, d_cnt, 32, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(h, ASM_ENODEVICE, "asm_stream_seq_file: counters copy failed");
+#undef STREAM_TRY
+    cleanup();
+    stats->pairs = done_pairs, stats->chunks = chunks, stats->bytes = (int64_t)bytes_total, stats->max_length = maxlen;
+    stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    stats->seconds_read = read_seconds;
+    if (!do_nw) stats->counters[0] = (unsigned long long)done_pairs;
+    return rc;
+}
+
+/* ---------------------------------------------------------------------------------------------------- */
 int asm_device_malloc(asm_handle* h, size_t bytes, void** d_ptr) {
     if (!h || !d_ptr) return fail(h, ASM_EINVAL, "asm_device_malloc: NULL argument");
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipMalloc(d_ptr, bytes ? bytes : 1));
+    HIPCHK(h, pool_alloc(h, d_ptr, bytes ? bytes : 1));
     return ASM_OK;
 }
 int asm_device_free(asm_handle* h, void* d_ptr) {
     if (!h) return fail(h, ASM_EINVAL, "asm_device_free: NULL handle");
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipFree(d_ptr));
+    pool_free(h, d_ptr); /* recycled in stream order: work already enqueued on the handle's stream may still use it */
     return ASM_OK;
 }
 int asm_memcpy_d2h(asm_handle* h, void* dst, const void* d_src, size_t bytes) {

@@ -1,7 +1,7 @@
 // asm-bench — the counterpart of the reference's `hurdle-matrix-benchmark` (GASMA/benchmark/benchmark.cpp:12-32):
 // generate (or read) a ">read\n<ref\n" file, run NW + LEAP + Greedy over it, print the results block.
 //   asm-bench [--file path | --n N --len L --err E --seed S] [--k K --x X --o O --e E] [--mode sequential|clean]
-//             [--answers path]
+//             [--answers path] [--stream [--chunk-mb M]]      --stream: the file goes through asm_stream_seq_file
 //   asm-bench --pair READ REF [--k K]                                     the per-pair classes of the reference on one pair
 //                                                                        (hurdle_matrix reset/run/get_cost/get_CIGAR, LV, SIMD_ED)
 //   asm-bench --leap-simd ERROR [--shd 0|1] [--batch-run N] < pairs      the LEAP_SIMD stdin filter driver
@@ -19,6 +19,8 @@ int main(int argc, char** argv) {
     std::string pair_read, pair_ref;
     bool pair_mode = false;
     long batch_run = 1000000;
+    bool stream = false;
+    long chunk_mb = 0;
     int n = 1000000, len = 100, k = 3, x = 1, o = 1, e = 1;
     float err = 0.10f;
     uint64_t seed = 2;
@@ -39,6 +41,8 @@ int main(int argc, char** argv) {
         else if (arg("--leap-simd")) leap_simd = atoi(argv[++i]);
         else if (arg("--shd")) shd = atoi(argv[++i]);
         else if (arg("--batch-run")) batch_run = atol(argv[++i]);
+        else if (!strcmp(argv[i], "--stream")) stream = true;
+        else if (arg("--chunk-mb")) chunk_mb = atol(argv[++i]);
         else {
             fprintf(stderr, "unknown argument %s\n", argv[i]);
             return 2;
@@ -72,9 +76,14 @@ int main(int argc, char** argv) {
             file = dataset.output();
         }
         benchmark bench(x, o, e, k, n, true, mode == "clean" ? ASM_GREEDY_CLEAN : ASM_GREEDY_SEQUENTIAL);  // benchmark.cpp:22
-        bench.read_string_file(file.c_str());
-        if (!answers.empty()) bench.read_answer_file(answers.c_str());
-        bench.run();
+        if (stream) {
+            if (!answers.empty()) bench.read_answer_file(answers.c_str());
+            bench.run_streamed(file.c_str(), (int64_t)chunk_mb << 20);
+        } else {
+            bench.read_string_file(file.c_str());
+            if (!answers.empty()) bench.read_answer_file(answers.c_str());
+            bench.run();
+        }
         bench.print();
     } catch (const std::exception& ex) {
         fprintf(stderr, "%s\n", ex.what());

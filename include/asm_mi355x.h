@@ -190,6 +190,31 @@ int asm_coverage(asm_handle* h, const asm_batch* b, const asm_params* p, const u
 int asm_align_batch(asm_handle* h, int aligner, int64_t n, const char* reads, const uint32_t* read_off,
                     const char* refs, const uint32_t* ref_off, const asm_params* p, int greedy_mode,
                     int32_t* penalties);
+/* ---- input side: the harness's file format (benchmark_utils.h:325-352) ---------------------------------------------------
+ * Line 2i = one marker character + read i, line 2i+1 = one marker character + reference i ('>' and '<' as Dataset writes
+ * them, benchmark_dataset.h:229,234; the first character of every line is skipped blindly, :337,:343).
+ * asm_batch_from_text: a batch out of such a text held in host memory; the raw bytes go to the GPU as they are and are
+ * parsed there (newline index, offsets, gather: csrc/asm_ingest.h). */
+int asm_batch_from_text(asm_handle* h, const char* text, size_t nbytes, int greedy_mode, asm_batch** out);
+/* asm_stream_seq_file: `read_string_file` + `run` for a file of any size, in chunks of about chunk_bytes (0 = 64 MiB): reader
+ * threads fill pinned buffers (three in rotation) and cut them at pair boundaries, the raw bytes are copied to HBM on a copy
+ * stream while the chunk before is parsed, packed and aligned on the handle's stream, and results of the chunk before that are
+ * handed over.  aligner_mask: bit 0 NW, 1 LEAP, 2 Greedy.  nw / leap / greedy: host arrays of out_cap entries (or NULL),
+ * pair i of the file at index i.  answers (optional, host, n_answers entries): read_answer_file's integers
+ * (benchmark_utils.h:358-368; INT32_MIN = "use the NW penalty").  With ASM_GREEDY_SEQUENTIAL the stale-tail chain of
+ * hurdle_matrix.h:136-137 runs through the chunk boundaries, so the result equals the reference run over the whole file.
+ * max_pairs > 0 stops after that many pairs (benchmark's max_test_num, benchmark_utils.h:331).  Synchronous. */
+typedef struct asm_stream_stats {
+    int64_t pairs, chunks, bytes;       /* pairs aligned, chunks shipped, file bytes shipped to the GPU                   */
+    unsigned long long counters[4];     /* total_tests, nw_correct, LEAP_correct, greedy_correct (benchmark_utils.h:249-255) */
+    double seconds;                     /* wall clock of the whole call                                                  */
+    double seconds_read;                /* of which the reader threads were busy (file -> pinned memory, newline count)    */
+    int32_t max_length, reserved_;
+} asm_stream_stats;
+int asm_stream_seq_file(asm_handle* h, const char* path, const asm_params* p, int greedy_mode, int aligner_mask,
+                        int64_t chunk_bytes, int64_t max_pairs, int32_t* nw, int32_t* leap, int32_t* greedy, int64_t out_cap,
+                        const int32_t* answers, int64_t n_answers, asm_stream_stats* stats);
+
 /* ---- filtering stage in front of the aligners: bit-parallel LEAP (SIMD_ED) and SHD ------------------------------
  * Replaces, per pair of the batch, the stdin filter driver's sequence (GASMA/benchmark/LEAP_SIMD/main.cpp:95-101,
  * 186-195): SIMD_ED::init_levenshtein(ed_threshold, ED_GLOBAL, shd_enable) once, then load_reads(read, ref,
