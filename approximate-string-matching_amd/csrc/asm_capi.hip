@@ -628,7 +628,7 @@ static int batch_resolve_tails(asm_handle* h, asm_batch* b, const uint8_t* init2
     HIPCHK(h, launch_pack(h, b, nullptr, b->d_tail_g0, b->d_tail_l0, one, nullptr));
     hipLaunchKernelGGL(tails_chunk_kernel, dim3((unsigned)nchunks), dim3(256), 0, h->stream, b->d_tail_g0, b->d_tail_l0, (long)b->n,
                        1, d_last);
-    hipLaunchKernelGGL(tails_carry_kernel, dim3(1), dim3(256), 0, h->stream, d_last, d_carry, nchunks, init,
+    hipLaunchKernelGGL(tails_carry_kernel, dim3(1), dim3(256 * TAIL_CARRY_SEGS), 0, h->stream, d_last, d_carry, nchunks, init,
                        summary256 ? d_sum : (uint8_t*)nullptr);
     if (emit)
         hipLaunchKernelGGL(tails_emit_kernel, dim3((unsigned)nchunks), dim3(256), 0, h->stream, b->d_tail_g0, b->d_tail_l0,

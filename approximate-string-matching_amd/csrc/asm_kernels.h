@@ -987,8 +987,14 @@ __global__ __launch_bounds__(LEAP_GEN_THREADS) void nw_wfa_kernel(const uint4* _
             }
             const int bound = 2 * o + (2 * K - adf) * ext;
             result = -1;
+            // every ring slot starts as "never reached": score s only sweeps the diagonals a gap of that cost can reach,
+            // |d| <= (s - o) / ext + 1 (a bound that never shrinks), and their neighbours are read before they are ever written
+            for (int q = 0; q < gm; q++)
 #pragma unroll
-            for (int j = 0; j < NL; j++) r_m[j * T] = -2, r_i[j * T] = -2, r_d[j * T] = -2;
+                for (int j = 0; j < NL; j++) r_m[q * SLOT + j * T] = -2;
+            for (int q = 0; q < gi; q++)
+#pragma unroll
+                for (int j = 0; j < NL; j++) r_i[q * SLOT + j * T] = -2, r_d[q * SLOT + j * T] = -2;
             {
                 const int e0 = vw_next_one<W64>(mask[K], 0); /* <= min(m, n) */
                 r_m[K * T] = (short)e0;
@@ -1003,10 +1009,12 @@ __global__ __launch_bounds__(LEAP_GEN_THREADS) void nw_wfa_kernel(const uint4* _
                 short* const i_w = r_i + (s & (gi - 1)) * SLOT;
                 short* const d_w = r_d + (s & (gi - 1)) * SLOT;
                 const bool has_o = s >= o, has_e = s >= ext, has_x = s >= x;
+                const int dmax = s < o ? 0 : (s - o) / ext + 1; /* wave-uniform: every thread is at the same score */
                 int done = 0;
 #pragma unroll
                 for (int j = 0; j < NL; j++) {
                     const int d = j - K;
+                    if ((d < 0 ? -d : d) > dmax) continue;
                     const int m_lo = (j > 0 && has_o) ? (int)m_o[(j > 0 ? j - 1 : 0) * T] : -2;
                     const int i_lo = (j > 0 && has_e) ? (int)i_e[(j > 0 ? j - 1 : 0) * T] : -2;
                     const int m_hi = (j < NL - 1 && has_o) ? (int)m_o[(j < NL - 1 ? j + 1 : j) * T] : -2;

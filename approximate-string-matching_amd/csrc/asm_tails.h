@@ -9,7 +9,7 @@
 // sits in slot SRC^-1[s] when pair t+1 is converted — unless pair t+1's string is long enough to overwrite it.  So
 // each of the 128 slots of a side starts a *trajectory* s, SRC^-1[s], SRC^-1[SRC^-1[s]], ... that carries "the code
 // of the last character written on this trajectory".  SRC has order 10 (cycles of length 1, 2, 5, 10), so after any
-// multiple of 10 pairs every trajectory is back in its starting slot; with chunks of 2560 pairs the trajectories of
+// multiple of 10 pairs every trajectory is back in its starting slot; with chunks of 640 pairs the trajectories of
 // consecutive chunks line up by thread index and the carried state is just a 2-bit code:
 //   pass 1  tails_chunk_kernel : per chunk and trajectory, the code of the last write inside the chunk (or none)
 //   pass 2  tails_carry_kernel : exclusive "last write wins" prefix over chunks (initial buffers = NUL, code 00)
@@ -22,9 +22,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define TAIL_CHUNK 2560 /* pairs per chunk: a multiple of 10 (the order of SRC) and of TAIL_SUB */
+#define TAIL_CHUNK 640  /* pairs per chunk: a multiple of 10 (the order of SRC); 10^6 pairs = 1563 workgroups, one round of the chip */
 #define TAIL_SUB 256    /* pairs whose tail planes are accumulated in LDS at a time */
-#define TAIL_BATCH 8    /* pairs whose plane words are fetched ahead */
+#define TAIL_BATCH 16   /* pairs whose plane words are fetched ahead (the walk is a chain of dependent round trips to HBM) */
 #define TAIL_NONE 0xFFu
 
 // SRC^-1: SRC[q] = 8*(q & 15) + P[q >> 4] and P is an involution, so q = (P[y & 7] << 4) | (y >> 3).
@@ -106,17 +106,51 @@ __global__ __launch_bounds__(256) void tails_chunk_kernel(const uint4* __restric
 struct TailState { /* passed by value: no host buffer has to outlive the enqueue */
     uint8_t code[256];
 };
-__global__ __launch_bounds__(256) void tails_carry_kernel(const uint8_t* __restrict__ chunk_last,
-                                                          uint8_t* __restrict__ carry_in, long nchunks,
-                                                          TailState init, uint8_t* __restrict__ summary) {
-    uint32_t cur = (uint32_t)init.code[threadIdx.x]; /* a file starts with NUL bytes: code 00 */
+// `init` ([256] = [side][slot]): the codes the two buffers hold before the first pair of this batch — zeros (NUL
+// bytes) for a batch that starts a file, the state after the previous shard/chunk otherwise (asm_tail_state_advance).
+// `summary` (optional, [256]): per trajectory, indexed by its slot before the first pair, the code of the last character the
+// batch wrote on it, or TAIL_NONE when the batch never touched it — the batch's whole effect on the buffers.
+// One workgroup of 1024 threads = 256 trajectories x 4 segments of the chunk sequence: every thread first finds the last
+// write inside its segment, the four meet in LDS, then every thread replays its segment from the right carry-in — two walks of
+// nchunks / 4 entries with 16 independent loads in flight, instead of one dependent walk over all chunks.
+#define TAIL_CARRY_SEGS 4
+__global__ __launch_bounds__(256 * TAIL_CARRY_SEGS) void tails_carry_kernel(const uint8_t* __restrict__ chunk_last,
+                                                                            uint8_t* __restrict__ carry_in, long nchunks,
+                                                                            TailState init, uint8_t* __restrict__ summary) {
+    __shared__ uint8_t s_seg[TAIL_CARRY_SEGS][256];
+    const int tr = threadIdx.x & 255, seg = threadIdx.x >> 8;
+    const long per = (nchunks + TAIL_CARRY_SEGS - 1) / TAIL_CARRY_SEGS;
+    const long c0 = seg * per, c1 = c0 + per < nchunks ? c0 + per : nchunks;
     uint32_t last = TAIL_NONE;
-    for (long c = 0; c < nchunks; c++) {
-        const uint32_t s = chunk_last[c * 256 + threadIdx.x];
-        carry_in[c * 256 + threadIdx.x] = (uint8_t)cur;
-        if (s != TAIL_NONE) cur = s, last = s;
+    for (long c = c0; c < c1; c += 16) {
+        uint32_t v[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = c + q < c1 ? chunk_last[(c + q) * 256 + tr] : TAIL_NONE;
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+            if (v[q] != TAIL_NONE) last = v[q];
     }
-    if (summary) summary[threadIdx.x] = (uint8_t)last;
+    s_seg[seg][tr] = (uint8_t)last;
+    __syncthreads();
+    uint32_t cur = (uint32_t)init.code[tr]; /* a file starts with NUL bytes: code 00 */
+    for (int q = 0; q < seg; q++)
+        if (s_seg[q][tr] != TAIL_NONE) cur = s_seg[q][tr];
+    for (long c = c0; c < c1; c += 16) {
+        uint32_t v[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = c + q < c1 ? chunk_last[(c + q) * 256 + tr] : TAIL_NONE;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            if (c + q < c1) carry_in[(c + q) * 256 + tr] = (uint8_t)cur;
+            if (v[q] != TAIL_NONE) cur = v[q];
+        }
+    }
+    if (summary && seg == TAIL_CARRY_SEGS - 1) {
+        uint32_t all = TAIL_NONE;
+        for (int q = 0; q < TAIL_CARRY_SEGS; q++)
+            if (s_seg[q][tr] != TAIL_NONE) all = s_seg[q][tr];
+        summary[tr] = (uint8_t)all;
+    }
 }
 
 // Host: where the trajectory that starts in `slot` sits after n pairs (SRC has order 10).

@@ -77,8 +77,11 @@ def isa_mix(kernel_short_name, rows):
     valu = collections.Counter(o for o in ops if o.startswith("v_"))
 
     def cyc(name):
+        # "cycles_span": first wave's loop start to last wave's loop end over (waves per SIMD x instructions per wave) — what the
+        # SIMD needs per instruction with 8 waves resident.  (The per-wave figure "cycles" undercounts: issue arbitration is
+        # oldest-first, so the waves of a SIMD finish one after the other, not together.)
         r = rows.get(name + "@8")
-        return r["cycles"] if r else None
+        return r["cycles_span"] if r else None
 
     table = {"v_xor_b32": "k_xor", "v_add_u32": "k_add", "v_sub_u32": "k_add", "v_subrev_u32": "k_add", "v_and_b32": "k_and",
              "v_or_b32": "k_and", "v_not_b32": "k_not", "v_mov_b32": "c_mov", "v_lshlrev_b32": "k_shl", "v_lshrrev_b32": "k_shr_v",
@@ -110,7 +113,7 @@ def isa_mix(kernel_short_name, rows):
         weighted += cnt * c
     return {"cycles_per_inst_mix": weighted / total if total else None, "static_valu_instructions": int(total),
             "unlisted_ops_priced_as_generic_vop3": dict(unknown.most_common(12)),
-            "note": "static histogram of the kernel's ISA, each opcode priced with its ubench row at 8 waves/SIMD"}
+            "note": "static histogram of the kernel's ISA, each opcode priced with its ubench row (cycles_span, 8 waves/SIMD)"}
 
 
 def main():
