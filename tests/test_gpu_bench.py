@@ -68,3 +68,32 @@ def test_more_ranks_than_gpus_is_refused(asm):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--pairs", "1000", "--steps", "1"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_cxx_harness_multi_gpu_mode_and_streaming(asm, oracle, tmp_path):
+    """asm-bench, the C++ host over the same C ABI: `--gpus N` (one thread and one handle per GPU, RCCL all-reduce of the four
+    counters on the stream the kernels run on; N = 1 on this box, N + 1 refused) and `--stream` (the file through
+    asm_stream_seq_file).  Percentages equal the oracle's counts exactly."""
+    import re
+
+    exe = os.path.join(ROOT, "approximate-string-matching_amd", "asm-bench")
+    n, steps = 20000, 3
+    r = subprocess.run([exe, "--gpus", "1", "--n", str(n), "--steps", str(steps), "--mode", "clean"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = _expected_counts(asm, oracle, 0, n)
+    assert f"Total number of alignments: {n * steps} " in r.stdout
+    got = [float(v) for v in re.findall(r"\| (\d+\.\d+) %", r.stdout)]
+    assert got == [100.0, round(100.0 * want[2] / n, 3), round(100.0 * want[3] / n, 3)], r.stdout
+    r = subprocess.run([exe, "--gpus", str(asm.device_count() + 1), "--n", "1000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "GPU(s) visible" in r.stderr
+    # --stream: generate the reference-shaped file, then stream it in 1 MiB chunks (sequential mode = the reference as run)
+    cfg, _, params = asm.workload("C2")
+    hb = asm.generate_pairs(cfg, 0, n)
+    path = str(tmp_path / "pairs.seq")
+    hb.write_seq_file(path)
+    r = subprocess.run([exe, "--file", path, "--n", str(n), "--stream", "--chunk-mb", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    nw, leap, greedy = oracle.nw(hb), oracle.leap(hb, 3), oracle.greedy(hb, 3, mode=0)
+    got = [float(v) for v in re.findall(r"\| (\d+\.\d+) %", r.stdout)]
+    assert got[:3] == [100.0, round(100.0 * float((leap == nw).mean()), 3), round(100.0 * float((greedy == nw).mean()), 3)], r.stdout
+    assert "[Streamed] %d pairs" % n in r.stdout
