@@ -559,8 +559,9 @@ class Engine:
     def run_benchmark_async(self, batch: DeviceBatch, params: Params, d_nw: Optional[int], d_leap: Optional[int],
                             d_greedy: Optional[int], d_counters: Optional[int], repack: bool = True,
                             d_answers: Optional[int] = None) -> None:
-        """`_run_benchmark` over the whole resident batch (pack, NW, LEAP, Greedy, counters) in one call."""
-        self._chk(self.lib.asm_run_benchmark_async(self.h, batch.ptr, ctypes.byref(params), 1 if repack else 0, d_nw,
+        """`_run_benchmark` over the whole resident batch (pack, NW, LEAP, Greedy, counters) in one call.  repack: False / True
+        (pack in stream order) / 2 (pipelined: this call's pack overlaps the previous call's aligners)."""
+        self._chk(self.lib.asm_run_benchmark_async(self.h, batch.ptr, ctypes.byref(params), int(repack), d_nw,
                                                    d_leap, d_greedy, d_answers, d_counters))
 
     # ---- timing ----

@@ -36,6 +36,8 @@ struct asm_handle {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;    /* asm_run_benchmark_async runs Greedy beside the NW -> LEAP chain */
+    hipStream_t pack_stream = nullptr;    /* ... and, with repack = 2, packs for this call while the previous call still aligns */
+    hipEvent_t ev_packed = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap = true;                  /* ASM_OVERLAP=0: everything on one stream */
     std::string err;
@@ -151,6 +153,13 @@ struct asm_batch {
     uint32_t* d_lens = nullptr; /* in bucketed order */
     uint32_t* d_order = nullptr; /* bucketed slot -> pair index (null: identity) */
     uint32_t* d_pos = nullptr;   /* pair index -> bucketed slot (null: identity) */
+    /* pipelined repack (asm_run_benchmark_async, repack = 2): a second set of planes/lens that the next call's pack fills
+     * while this call's aligners still read the current one */
+    uint4* d_planes_alt = nullptr;
+    uint32_t* d_lens_alt = nullptr;
+    size_t planes_total = 0;     /* uint4 entries in d_planes */
+    hipEvent_t ev_consumed[2] = {nullptr, nullptr}; /* aligners of the call that used buffer q are done */
+    int cur = 0;
     uint4* d_tails = nullptr;    /* sequential mode: stale-tail planes, uint4[4][n] in input order */
     uint4* d_tail_g0 = nullptr;  /* tail resolver scratch (asm_tails.h), allocated on first use: clean granule 0 in input order, */
     uint32_t* d_tail_l0 = nullptr; /* its lengths, */
@@ -427,6 +436,8 @@ int asm_create(asm_handle** out, int device) {
     HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
     HIPCHK(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->pack_stream, hipStreamNonBlocking));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_packed, hipEventDisableTiming));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     hipDeviceProp_t prop;
@@ -456,6 +467,8 @@ int asm_destroy(asm_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+    if (h->pack_stream) (void)hipStreamDestroy(h->pack_stream);
+    if (h->ev_packed) (void)hipEventDestroy(h->ev_packed);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->d_todo) (void)hipFree(h->d_todo);
@@ -557,6 +570,10 @@ static void batch_release(asm_batch* b) {
     pool_free(b->owner, b->d_ref_off);
     pool_free(b->owner, b->d_planes);
     pool_free(b->owner, b->d_lens);
+    pool_free(b->owner, b->d_planes_alt);
+    pool_free(b->owner, b->d_lens_alt);
+    for (hipEvent_t ev : b->ev_consumed)
+        if (ev) (void)hipEventDestroy(ev);
     pool_free(b->owner, b->d_order);
     pool_free(b->owner, b->d_pos);
     pool_free(b->owner, b->d_tails);
@@ -711,6 +728,7 @@ static int batch_finish(asm_handle* h, asm_batch* b) {
         }
         b->pb.nb = b->nb;
         b->pb.start[b->nb] = slot;
+        b->planes_total = plane_total ? plane_total : 1;
         TRY(pool_alloc(h, (void**)&b->d_planes, sizeof(uint4) * (plane_total ? plane_total : 1)));
         TRY(pool_alloc(h, (void**)&b->d_lens, sizeof(uint32_t) * (size_t)(n > 0 ? n : 1)));
         for (int q = 0; q < b->nb; q++) {
@@ -1459,6 +1477,7 @@ int asm_profile_read(asm_handle* h, float* ms, int cap_calls, int* n_calls) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->side_stream) HIPCHK(h, hipStreamSynchronize(h->side_stream));
+    if (h->pack_stream) HIPCHK(h, hipStreamSynchronize(h->pack_stream));
     const int n = (int)h->prof_mask.size();
     *n_calls = n;
     for (int c = 0; c < n && c < cap_calls; c++)
@@ -1486,7 +1505,40 @@ int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, in
         pmask |= 1u << (q);                                                  \
     }
     hipStream_t main_stream = h->stream;
-    if (repack) {
+    bool pipelined = false;
+    if (repack == 2 && b->n > 0) {
+        /* Pipelined repack: pack fills the OTHER set of planes on its own stream, so it runs beside the aligners of the previous
+         * call (which read the current set) instead of behind them; this call's aligners wait for it.  The set it fills was last
+         * read two calls ago (ev_consumed).  The caller guarantees that nothing enqueued since the previous call changes what
+         * pack reads (the resident ASCII, the tails). */
+        HIPCHK(h, hipSetDevice(h->device));
+        if (!b->d_planes_alt) {
+            HIPCHK(h, pool_alloc(h, (void**)&b->d_planes_alt, sizeof(uint4) * b->planes_total));
+            HIPCHK(h, pool_alloc(h, (void**)&b->d_lens_alt, sizeof(uint32_t) * (size_t)b->n));
+            for (hipEvent_t& ev : b->ev_consumed) HIPCHK(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            HIPCHK(h, hipEventRecord(b->ev_consumed[0], main_stream)); /* everything enqueued so far (the batch's creation) */
+            HIPCHK(h, hipEventRecord(b->ev_consumed[1], main_stream));
+        }
+        const int nxt = b->cur ^ 1;
+        std::swap(b->d_planes, b->d_planes_alt);
+        std::swap(b->d_lens, b->d_lens_alt);
+        b->cur = nxt;
+        for (int q = 0; q < b->nb; q++) {
+            b->bk[q].planes = b->d_planes + b->pb.plane_off[q];
+            b->bk[q].lens = b->d_lens + b->pb.start[q];
+        }
+        HIPCHK(h, hipStreamWaitEvent(h->pack_stream, b->ev_consumed[nxt], 0));
+        PROF(0, 0, h->pack_stream)
+        h->stream = h->pack_stream;
+        rc = asm_batch_pack_async(h, b);
+        h->stream = main_stream;
+        PROF(0, 1, h->pack_stream)
+        if (!rc) {
+            HIPCHK(h, hipEventRecord(h->ev_packed, h->pack_stream));
+            HIPCHK(h, hipStreamWaitEvent(main_stream, h->ev_packed, 0));
+        }
+        pipelined = true;
+    } else if (repack) {
         PROF(0, 0, main_stream)
         rc = asm_batch_pack_async(h, b);
         PROF(0, 1, main_stream)
@@ -1524,6 +1576,7 @@ int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, in
     }
 #undef PROF
     if (pe) h->prof_mask.push_back(pmask);
+    if (pipelined && !rc) HIPCHK(h, hipEventRecord(b->ev_consumed[b->cur], main_stream)); /* Greedy's stream has joined above */
     if (!rc && d_counters && d_nw) rc = asm_accuracy_async(h, d_nw, d_leap, d_greedy, d_answers, b->n, d_counters);
     return rc;
 }

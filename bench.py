@@ -32,6 +32,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md §Chip-level parameters)
 PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+# repack mode of the timed step: 1 = strictly in order (default), 2 = pipelined (the pack of step s+1 runs beside the aligners of
+# step s on its own stream; ASM_PACK_PIPELINE=1).  Measured at C2: 0.280 ms/step pipelined against 0.263 in order — pack's
+# workgroups take CUs away from the persistent Greedy kernel, whose waves own static slices of the batch (0.151 -> 0.222 ms).
+PACK_MODE = 2 if os.environ.get("ASM_PACK_PIPELINE", "0") == "1" else 1
 KERNEL_SOURCES = ("approximate-string-matching_amd/csrc", "approximate-string-matching_amd/Makefile")
 
 
@@ -258,7 +262,7 @@ def run(args, asm, eng, torch, dist, stream, rank, world, cfg, params, first, n,
     def step(timers=None, b=batch, repack=True):
         if timers is None:
             # `_run_benchmark` for the whole batch: pack, aligners, counters — one C-ABI call, five launches
-            eng.run_benchmark_async(b, params, d_nw, d_leap, d_greedy, d_cnt, repack=repack)
+            eng.run_benchmark_async(b, params, d_nw, d_leap, d_greedy, d_cnt, repack=(PACK_MODE if repack else 0))
             return
         seq = [("pack", lambda: eng.pack_async(b))]
         for a in aligners:

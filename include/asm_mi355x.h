@@ -247,7 +247,11 @@ int asm_count_equal_async(asm_handle* h, const int32_t* d_a, const int32_t* d_b,
 int asm_accuracy_async(asm_handle* h, const int32_t* d_nw, const int32_t* d_leap, const int32_t* d_greedy,
                        const int32_t* d_answers, int64_t n, unsigned long long* d_counters);
 /* `_run_benchmark` for a whole resident batch in one call (benchmark_utils.h:231-259): optional re-pack of the
- * resident ASCII, then every aligner whose output pointer is non-NULL, then the counters.  Enqueue only. */
+ * resident ASCII, then every aligner whose output pointer is non-NULL, then the counters.  Enqueue only.
+ * repack: 0 = use the planes as they are; 1 = pack first, in stream order; 2 = pack first, PIPELINED: the pack of this call
+ * fills a second set of planes on its own stream and so overlaps the aligners of the previous call (pack waits on memory for
+ * half of its time, the aligners are instruction-bound); this call's aligners wait for it.  With 2 the caller guarantees that
+ * nothing it enqueued since the previous call on this batch changes what pack reads. */
 int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, int repack, int32_t* d_nw,
                             int32_t* d_leap, int32_t* d_greedy, const int32_t* d_answers,
                             unsigned long long* d_counters);

@@ -622,6 +622,34 @@ def test_greedy_semi_global(asm, engine, oracle, wl, n, k, pen):
         engine.align(batch, asm.GREEDY, asm.Params.default(k=k, alignment_type=2))
 
 
+@pytest.mark.parametrize("wl,n", [("C2", 30000), ("C5", 12000)])
+def test_pipelined_repack_gives_the_same_results(asm, engine, oracle, wl, n):
+    """asm_run_benchmark_async with repack = 2: the pack of call s+1 fills a second set of planes on its own stream while the
+    aligners of call s still read the first.  Many back-to-back calls without a sync in between (so that they really overlap),
+    mixed with in-order repacks and plain runs: penalties and counters equal the oracle's every time."""
+    cfg, _, params = asm.workload(wl)
+    hb = asm.generate_pairs(cfg, 13, n)
+    batch = engine.upload(hb, asm.GREEDY_SEQUENTIAL)
+    d = [engine.malloc(4 * n) for _ in range(3)]
+    d_cnt = engine.malloc(32)
+    engine.memset_async(d_cnt, 0, 32)
+    calls = [2, 2, 2, 1, 2, 0, 2, 2, 1, 1, 2]
+    for mode in calls:
+        engine.run_benchmark_async(batch, params, d[0], d[1], d[2], d_cnt, repack=mode)
+    nw, leap, greedy = oracle.nw(hb), oracle.leap(hb, params.k), oracle.greedy(hb, params.k, mode=0)
+    ok = np.maximum(*hb.lengths()) <= 256
+    assert np.array_equal(engine.to_host(d[0], n), nw)
+    assert np.array_equal(engine.to_host(d[1], n)[ok], leap[ok])
+    assert np.array_equal(engine.to_host(d[2], n), greedy)
+    cnt = engine.to_host(d_cnt, 4, np.uint64)
+    got_leap = engine.to_host(d[1], n)
+    assert cnt.tolist() == [len(calls) * n, len(calls) * n, len(calls) * int((got_leap == nw).sum()), len(calls) * int((greedy == nw).sum())]
+    # the batch is still a normal batch afterwards
+    assert np.array_equal(engine.align(batch, asm.GREEDY, params), greedy)
+    for x in d + [d_cnt]:
+        engine.free(x)
+
+
 def test_profile_events_inside_run_benchmark(asm, engine):
     """asm_profile_enable / asm_profile_read: per-kernel HIP events recorded by the library inside asm_run_benchmark_async
     (what bench.py uses for the dominant kernel's duration inside its timed region)."""
