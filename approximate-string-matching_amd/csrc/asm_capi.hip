@@ -1155,7 +1155,7 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
 #undef LEAP_BAND
         } else if (!unit && h->leap_band && h->wave_kernels &&
                    leap_band_general_lds((b.maxlen + 31) / 32, (int)p->k, RingGeometry(p->x, p->o, p->e).gm,
-                                         RingGeometry(p->x, p->o, p->e).gi, b.maxlen + 2 <= 255 ? 1 : 2) <= 64 * 1024) {
+                                         RingGeometry(p->x, p->o, p->e).gi, b.maxlen + 2 <= 255 ? 1 : 2) <= 80 * 1024) { /* two workgroups per CU at least */
             /* wide band, general penalties: thread per pair, generation rings and planes in LDS (asm_wave.h) */
             const RingGeometry rg(p->x, p->o, p->e);
             const int w32 = (b.maxlen + 31) / 32;

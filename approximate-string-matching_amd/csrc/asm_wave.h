@@ -347,8 +347,13 @@ template <int W32, typename EnT>
 static inline hipError_t launch_leap_band_general(hipStream_t stream, const uint4* planes, const uint32_t* lens, int64_t n, int w4,
                                                   int k, int x, int o, int e, int gm, int gi, OutMap out) {
     const dim3 grid((unsigned)((n + LEAP_BANDG_THREADS - 1) / LEAP_BANDG_THREADS)), block(LEAP_BANDG_THREADS);
-    hipLaunchKernelGGL((leap_band_general_kernel<W32, EnT>), grid, block, leap_band_general_lds(W32, k, gm, gi, sizeof(EnT)), stream,
-                       planes, lens, (long)n, w4, k, x, o, e, gm, gi, out);
+    const size_t lds = leap_band_general_lds(W32, k, gm, gi, sizeof(EnT));
+    if (lds > 64 * 1024) { /* deep rings at a wide band (e.g. (4,6,2) at k = 30): a CU's 160 KB still hold two such workgroups */
+        const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&leap_band_general_kernel<W32, EnT>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e2 != hipSuccess) return e2;
+    }
+    hipLaunchKernelGGL((leap_band_general_kernel<W32, EnT>), grid, block, lds, stream, planes, lens, (long)n, w4, k, x, o, e, gm, gi, out);
     return hipGetLastError();
 }
 
