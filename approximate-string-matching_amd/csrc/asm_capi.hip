@@ -1022,7 +1022,15 @@ int asm_batch_resolve_tails(asm_handle* h, asm_batch* b, const uint8_t* state) {
 }
 
 int asm_batch_free(asm_handle* h, asm_batch* b) {
-    if (h) (void)hipSetDevice(h->device);
+    if (!b) return ASM_OK;
+    if (!h) { /* the handle is gone (asm_destroy released every block of its pool, this batch's included): only the record is left */
+        for (hipEvent_t ev : b->ev_consumed)
+            if (ev) (void)hipEventDestroy(ev);
+        delete b;
+        return ASM_OK;
+    }
+    (void)hipSetDevice(h->device);
+    b->owner = h;
     batch_release(b);
     return ASM_OK;
 }

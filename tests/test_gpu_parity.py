@@ -695,3 +695,18 @@ def test_per_pair_classes_of_the_reference(asm, oracle):
         assert out[1] == "leap pass %d ED %d" % (1 if leap >= 0 else 0, leap), (key, out[1])
         ed, _, ps = oracle.simd_ed(hb, 3, True, 0, (0, 0, 0))
         assert out[2] == "simd_ed pass %d ED %d" % (int(ps[0]), int(ed[0])), (key, out[2])
+
+
+def test_batches_may_outlive_their_engine(asm):
+    """Device blocks of a batch belong to its handle's pool: destroying the handle first (Python's garbage collector does, at
+    interpreter exit) must leave the batch record freeable, and a second engine must work afterwards."""
+    cfg, _, params = asm.workload("C2")
+    eng = asm.Engine(0)
+    b1, b2 = eng.generate(cfg, 0, 5000), eng.upload(asm.generate_pairs(cfg, 0, 100))
+    d = eng.malloc(4 * 5000)
+    eng.align_async(b1, asm.GREEDY, params, d)
+    eng.close()
+    b1.free(), b2.free()
+    eng2 = asm.Engine(0)
+    assert eng2.align(eng2.generate(cfg, 0, 100), asm.NW, params).shape == (100,)
+    eng2.close()
