@@ -83,6 +83,7 @@ def pmc_for(pmc, short, pairs):
     for key in ("traffic_bytes", "fetch_bytes", "write_bytes", "insts_valu", "active_inst_valu", "thread_cycles_valu"):
         if k.get(key) is not None:
             out[key] = k[key] * scale
+    out["valu_mix"] = k.get("valu_mix")
     return out
 
 
@@ -98,11 +99,13 @@ def valu_roofline(entry, pmc, launch_ms):
     achieved = insts / (launch_ms * 1e-3)
     simds = pmc.get("simd_count", 1024)
     out = {"bound": "valu-issue", "insts_per_launch": insts, "achieved": achieved, "unit": "wave-instructions/s"}
-    mix = pmc.get("ubench", {})
-    if mix.get("cycles_per_inst_mix") and mix.get("sclk_hz"):
-        peak = simds * mix["sclk_hz"] / mix["cycles_per_inst_mix"]
+    ub, mix = pmc.get("ubench", {}), entry.get("valu_mix") or {}
+    if mix.get("cycles_per_inst_mix") and ub.get("sclk_hz"):
+        peak = simds * ub["sclk_hz"] / mix["cycles_per_inst_mix"]
         out["peak_measured_mix"] = {"peak": peak, "frac": achieved / peak, "cycles_per_inst": mix["cycles_per_inst_mix"],
-                                    "sclk_hz": mix["sclk_hz"], "source": mix.get("source")}
+                                    "sclk_hz": ub["sclk_hz"], "source": ub.get("source"),
+                                    "what": "this kernel's static instruction histogram priced with the measured issue cost of "
+                                            "each opcode (8 waves per SIMD, first loop start to last loop end)"}
     peak2 = simds * 2.4e9 / 2.0
     out["peak_arch_2cyc"] = {"peak": peak2, "frac": achieved / peak2}
     if entry.get("thread_cycles_valu") and entry.get("active_inst_valu"):

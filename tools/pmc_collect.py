@@ -56,17 +56,29 @@ def run_pass(name, counters, out_dir, bench_args):
     return agg
 
 
-def isa_mix(kernel_short_name, rows):
-    """Static instruction histogram of the named kernel (hipcc -S of the product source) weighted with the ubench rows."""
-    pkg = os.path.join(ROOT, "approximate-string-matching_amd")
-    out = "/tmp/_asm_capi.s"
-    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-S",
-                    "--cuda-device-only", "-o", out, "csrc/asm_capi.hip"], cwd=pkg, check=True, capture_output=True)
-    s = open(out).read()
+_ASM_TEXT = None
+
+
+def product_isa():
+    global _ASM_TEXT
+    if _ASM_TEXT is None:
+        pkg = os.path.join(ROOT, "approximate-string-matching_amd")
+        out = "/tmp/_asm_capi.s"
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-S",
+                        "--cuda-device-only", "-o", out, "csrc/asm_capi.hip"], cwd=pkg, check=True, capture_output=True)
+        _ASM_TEXT = open(out).read()
+    return _ASM_TEXT
+
+
+def isa_mix(kernel_name, rows):
+    """Static instruction histogram of the named kernel instantiation (hipcc -S of the product source) weighted with the ubench
+    rows."""
+    s = product_isa()
     best = None
+    want = kernel_name.replace(" ", "")
     for m in re.finditer(r"^(_Z[\w]+):\s*; @", s, re.M):
         dem = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
-        if dem.replace("void ", "").startswith(kernel_short_name):
+        if dem.replace("void ", "").replace(" ", "").startswith(want + "("):
             end = s.find(".Lfunc_end", m.start())
             best = s[m.end():end]
             break
@@ -116,12 +128,35 @@ def isa_mix(kernel_short_name, rows):
             "note": "static histogram of the kernel's ISA, each opcode priced with its ubench row (cycles_span, 8 waves/SIMD)"}
 
 
+def add_mixes(kernels, ubench):
+    """Every measured kernel gets the issue cost of ITS instruction mix (static histogram x ubench rows)."""
+    for short, e in kernels.items():
+        mix = isa_mix(e["kernel_name"], ubench["rows"])
+        if mix:
+            e["valu_mix"] = mix
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--remix", action="store_true",
+                    help="no GPU: recompute the per-kernel instruction-mix costs of an existing profiles/r02_pmc.json (same sources)")
     ap.add_argument("--head", default="unknown", help="git HEAD of the tree being measured (the box has no .git)")
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--steps", type=int, default=5)
     args = ap.parse_args()
+    if args.remix:
+        with open(bench.PMC_FILE) as fh:
+            doc = json.load(fh)
+        if doc.get("source_digest") != bench.kernel_source_digest():
+            raise SystemExit("the kernel sources changed since the counters were collected: re-run on the GPU box")
+        for k in ("cycles_per_inst_mix", "static_valu_instructions", "unlisted_ops_priced_as_generic_vop3", "note", "mix_kernel"):
+            doc["ubench"].pop(k, None)
+        add_mixes(doc["kernels"], doc["ubench"])
+        with open(bench.PMC_FILE, "w") as fh:
+            json.dump(doc, fh, indent=1)
+        for short, e in doc["kernels"].items():
+            print(short, e["kernel_name"], e.get("valu_mix", {}).get("cycles_per_inst_mix"))
+        return
     out_dir = os.path.join(ROOT, "gpurun_out", "final", "pmc")
     os.makedirs(out_dir, exist_ok=True)
     bench_args = ["--workload", args.workload, "--steps", str(args.steps), "--warmup", "1", "--no-cpu-baseline",
@@ -169,12 +204,8 @@ def main():
     with open(os.path.join(ROOT, "gpurun_out", "final", "valu_rates.txt"), "w") as fh:
         fh.write(txt)
     ub = json.loads(txt.strip().splitlines()[-1][len("JSON "):])
-    dom = max((k for k in kernels if k != "pack"), key=lambda k: kernels[k].get("wave_cycles") or 0, default=None)
     ubench = {"sclk_hz": ub["sclk_hz_median"], "rows": ub["rows"], "source": "tools/ubench/valu_rates.hip (profiles/r02_valu_rates.txt)"}
-    if dom:
-        mix = isa_mix(kernels[dom]["kernel_name"].split("<")[0], ub["rows"])
-        if mix:
-            ubench.update(mix, mix_kernel=kernels[dom]["kernel_name"])
+    add_mixes(kernels, ubench)
     doc = {"_comment": "written by tools/pmc_collect.py; HBM bytes = FETCH_SIZE KiB x 2 (gfx950 tallies 128-B requests at 64 B for "
                        "wide coalesced reads) + WRITE_SIZE KiB, per launch, mean over the launches of the run",
            "git_head": args.head, "source_digest": bench.kernel_source_digest(), "workload": args.workload, "pairs": pairs,
