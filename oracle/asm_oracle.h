@@ -7,9 +7,10 @@
  *
  * Pinning: tests/test_oracle_vs_reference.py diffs every function here against oracle/_ref/libasm_ref.so
  * (the real reference compiled in place, this container only) and tests/golden/ holds vectors generated
- * from that library by tests/golden/make_golden.py.  NW has no reference-side pin (parasail is absent
+ * from that library by tests/golden/make_golden.py.  NW: PARITY UNPINNED by reference vectors (parasail is absent
  * from the reference tree): its parity is by definition (Gotoh global affine distance),
- * cross-checked against plain Levenshtein DP for unit costs.
+ * cross-checked against plain Levenshtein DP for unit costs, and statistically against every accuracy and coverage line of
+ * the reference's README on pairs drawn the reference's way (asm_oracle_dataset.c; tests/test_oracle_golden.py).
  *
  * Batch layout used by every entry point: `reads`/`refs` are concatenated ASCII strings (no terminators),
  * `*_off` are n+1 prefix offsets (uint32), pair i is reads[read_off[i] .. read_off[i+1]).
