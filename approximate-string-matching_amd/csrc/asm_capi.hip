@@ -207,8 +207,15 @@ static hipError_t launch_persistent(asm_handle* h, Kern kern, int64_t n, Args...
     return hipGetLastError();
 }
 
+#ifdef GREEDY_DIAG
+static void* g_diag_buf = nullptr; /* diagnostic build only (never the shipped library): per-wave cycle stamps of the Greedy kernel */
+extern "C" void asm_diag_set_buffer(void* d) { g_diag_buf = d; }
+#endif
 template <int K>
 static hipError_t launch_greedy(asm_handle* h, const asm_bucket& b, const GreedyArgs& ga, OutMap out, CigarSink cig) {
+#ifdef GREEDY_DIAG
+    if (cig.ops == nullptr && g_diag_buf) cig.nops = (uint8_t*)g_diag_buf;
+#endif
     if (h->persist && ga.x == 1 && ga.o == 1 && ga.e == 1 && !ga.semi)
         return launch_persistent(h, greedy_persist_kernel<K, true>, b.n, (const uint4*)b.planes, (const uint32_t*)b.lens,
                                  (long)b.n, b.w4, ga, out, cig, h->refill_greedy);

@@ -473,7 +473,13 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_persist_kernel(const uint4* 
         if (KEEP_LF) lf_[j] = v_make(0, 0);
         sp[j] = -1, len[j] = 0, nsw[j] = 128, dst[j] = 0, sw[j] = nh[j] = 0;
     }
+#ifdef GREEDY_DIAG
+    unsigned long long dg_refill = 0, dg_step = 0, dg_iters = 0, dg_refills = 0, dg_lanes = 0, dg_t0 = __builtin_amdgcn_s_memtime();
+#endif
     for (;;) {
+#ifdef GREEDY_DIAG
+        const unsigned long long dg_a = __builtin_amdgcn_s_memtime();
+#endif
         const bool need = finished && !exhausted;
         // Refill lazily: the setup below costs about as much as a step, so wait until `refill_min` lanes are idle
         // (or nothing else is left to do) before paying for it.
@@ -524,6 +530,12 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_persist_kernel(const uint4* 
                 finished = false;
             }
         }
+#ifdef GREEDY_DIAG
+        const unsigned long long dg_b = __builtin_amdgcn_s_memtime();
+        dg_refill += dg_b - dg_a;
+        dg_iters++;
+        dg_lanes += __popcll(__ballot(active && !finished));
+#endif
         if (__ballot(active && !finished) == 0ull) break; /* wave-uniform: every lane has drained the queue */
         if (active && !finished) {
             // ---- _update_highway_list ----
@@ -597,7 +609,16 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_persist_kernel(const uint4* 
                 if (cur_col >= lane_destination(m, nn, ch)) finished = true;
             }
         }
+#ifdef GREEDY_DIAG
+        dg_step += __builtin_amdgcn_s_memtime() - dg_b;
+#endif
     }
+#ifdef GREEDY_DIAG
+    if ((threadIdx.x & 63) == 0 && cig.nops != nullptr && cig.ops == nullptr) { /* diag build: cig.nops doubles as the debug buffer */
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(cig.nops) + 8 * (((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+        dbg[0] = dg_refill, dbg[1] = dg_step, dbg[2] = dg_iters, dbg[3] = dg_lanes, dbg[4] = __builtin_amdgcn_s_memtime() - dg_t0;
+    }
+#endif
 }
 
 // --------------------------------------------------------------------------------------------------------
