@@ -73,6 +73,30 @@ def test_streamed_file_equals_the_whole_file_run(asm, engine, oracle, tmp_path, 
     assert list(st3.counters) == [n, int((nw == want).sum()), int((got[asm.LEAP] == want).sum()), int((greedy == want).sum())]
 
 
+def test_streaming_degenerate_files(asm, engine, oracle, tmp_path):
+    """An empty file, a lone read line, a file without a final newline, chunk size below one pair's text."""
+    p = asm.Params.default()
+    empty = str(tmp_path / "empty.seq")
+    open(empty, "w").close()
+    got, st = engine.stream_seq_file(empty, p)
+    assert st.pairs == 0 and st.chunks == 0 and all(v.size == 0 for v in got.values())
+    lone = str(tmp_path / "lone.seq")
+    with open(lone, "w") as fh:
+        fh.write(">ACGTACGTAC")
+    got, st = engine.stream_seq_file(lone, p, asm.GREEDY_CLEAN)
+    assert st.pairs == 1 and got[asm.NW].tolist() == [10]          # against an empty reference: gap of ten
+    cfg, _, _ = asm.workload("C1")
+    hb = asm.generate_pairs(cfg, 0, 500)
+    path = str(tmp_path / "nonl.seq")
+    hb.write_seq_file(path)
+    with open(path, "rb+") as fh:                                   # drop the final newline
+        fh.seek(-1, 2)
+        fh.truncate()
+    got, st = engine.stream_seq_file(path, p, asm.GREEDY_SEQUENTIAL, chunk_bytes=4096)   # 4 KiB chunks: ~20 pairs each
+    assert st.pairs == 500 and st.chunks >= 20
+    assert np.array_equal(got[asm.GREEDY], oracle.greedy(hb, 3, mode=0)) and np.array_equal(got[asm.LEAP], oracle.leap(hb, 3))
+
+
 def test_streaming_errors(asm, engine, tmp_path):
     with pytest.raises(asm.AsmError):
         engine.stream_seq_file(str(tmp_path / "missing.seq"), asm.Params.default())
