@@ -1,0 +1,61 @@
+"""A longer randomized GPU-vs-oracle campaign than the test-suite affords (development tool):
+PYTHONPATH=. python tools/fuzz_gpu.py [seconds] [seed].  Every aligner, every band width 1..50, random penalties, both Greedy tail
+modes and alignment types, CIGARs, coverage; uniform, mixed and ragged lengths.  Prints one line per case; exits 1 on a mismatch."""
+import sys, time
+import numpy as np
+import approximate_string_matching_amd as m
+from tests import oracle_binding
+from tests.util import random_ragged_batch, greedy_defined, leap_defined
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+orc = oracle_binding.load_oracle()
+orc.set_threads(16)
+eng = m.Engine(0)
+t0 = time.time()
+case = 0
+bad = 0
+while time.time() - t0 < budget:
+    case += 1
+    kind = rng.integers(0, 4)
+    n = int(rng.integers(500, 6000))
+    if kind == 0:
+        L = int(rng.integers(20, 300)); err = float(rng.choice([0.02, 0.05, 0.1, 0.2, 0.3]))
+        hb = m.generate_pairs(m.GenConfig.exact(int(rng.integers(1, 1 << 30)), L, err), 0, n); desc = f"exact L={L} err={err}"
+    elif kind == 1:
+        lo = int(rng.integers(1, 150)); hi = lo + int(rng.integers(0, 200))
+        hb = m.generate_pairs(m.GenConfig.exact(int(rng.integers(1, 1 << 30)), lo, 0.12, length_hi=min(hi, 400)), 0, n); desc = f"mixed {lo}-{hi}"
+    elif kind == 2:
+        hb = random_ragged_batch(m, int(rng.integers(1, 1 << 30)), min(n, 2000), 0, int(rng.integers(10, 300)), err=float(rng.choice([0.05, 0.15, 0.3]))); desc = "ragged"
+    else:
+        hb = m.generate_pairs(m.GenConfig.per_base(int(rng.integers(1, 1 << 30)), int(rng.integers(30, 250)), 0.03, 0.01, 0.01), 0, n); desc = "per-base"
+    k = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 14, 15, 16, 23, 30, 31, 32, 36, 39, 40, 50]))
+    unit = rng.random() < 0.5
+    x, o, e = (1, 1, 1) if unit else (int(rng.integers(1, 6)), 0, 0)
+    if not unit:
+        e = int(rng.integers(1, 4)); o = e + int(rng.integers(0, 5))
+    mode = int(rng.integers(0, 2)); semi = bool(rng.integers(0, 2)) and not unit
+    p = m.Params.default(k=k, x=x, o=o, e=e, alignment_type=1 if semi else 0)
+    batch = eng.upload(hb, mode)
+    gd, ld = greedy_defined(hb, k), leap_defined(hb)
+    res = []
+    got = eng.align(batch, m.NW, p); res.append(("nw", bool(np.array_equal(got, orc.nw(hb, x, o, e)))))
+    got = eng.align(batch, m.LEAP, p); res.append(("leap", bool(np.array_equal(got[ld], orc.leap(hb, k, x, o, e)[ld]))))
+    want, wcig = orc.greedy(hb, k, x, o, e, mode=mode, cigars=True, semi=semi)
+    cost, cig, nops = eng.greedy_with_cigar(batch, p, cap=255)
+    res.append(("greedy", bool(np.array_equal(cost[gd], want[gd]))))
+    res.append(("cigar", all(cig[i] == wcig[i] for i in np.nonzero(gd)[0] if nops[i] <= 255)))
+    if not semi and hb.n <= 3000:
+        cov = eng.coverage(batch, p, window=int(rng.choice([32, 64])), cap=255, want_nw_cigars=True)
+        pen, ncig = orc.nw_cigar(hb, x, o, e)
+        wc = orc.coverage(hb, wcig, 1, ncig, 3)
+        sel = np.nonzero(gd)[0]
+        res.append(("nwcigar", all(cov["nw_cigars"][i] == ncig[i] for i in range(hb.n) if len(ncig[i]) and cov["nw_cigars"][i].count("=") + cov["nw_cigars"][i].count("X") + cov["nw_cigars"][i].count("I") + cov["nw_cigars"][i].count("D") < 255)))
+        res.append(("cover", bool(np.array_equal(cov["cover"][sel], wc[sel])) and cov["undetermined"] == 0))
+    ok = all(v for _, v in res)
+    bad += 0 if ok else 1
+    print(f"case {case:3d} {desc:22s} n={hb.n:5d} k={k:2d} pen=({x},{o},{e}) mode={mode} semi={int(semi)}: " + " ".join(f"{a}={'ok' if v else 'FAIL'}" for a, v in res), flush=True)
+    batch.free()
+print("cases", case, "failed", bad)
+eng.close()
+sys.exit(1 if bad else 0)
