@@ -31,7 +31,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md §Chip-level parameters)
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")  # workload C2; other workloads: r02_pmc_<workload>.json
+
+
+def pmc_path(workload):
+    return PMC_FILE if workload == "C2" else os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % workload.lower())
 # repack mode of the timed step: 1 = strictly in order (default), 2 = pipelined (the pack of step s+1 runs beside the aligners of
 # step s on its own stream; ASM_PACK_PIPELINE=1).  Measured at C2: 0.280 ms/step pipelined against 0.263 in order — pack's
 # workgroups take CUs away from the persistent Greedy kernel, whose waves own static slices of the batch (0.151 -> 0.222 ms).
@@ -59,15 +63,17 @@ def kernel_source_digest():
 def load_pmc(workload):
     """Counters collected by tools/pmc_collect.py (separate rocprofv3 --pmc passes over this very script).  Returns
     (entry-per-kernel dict, meta) or (None, reason)."""
+    path = pmc_path(workload)
     try:
-        with open(PMC_FILE) as fh:
+        with open(path) as fh:
             d = json.load(fh)
     except (OSError, ValueError) as exc:
-        return None, f"no PMC file ({exc.__class__.__name__})"
+        return None, f"no PMC file {os.path.relpath(path, ROOT)} ({exc.__class__.__name__})"
     if d.get("source_digest") != kernel_source_digest():
-        return None, f"{os.path.relpath(PMC_FILE, ROOT)} was measured on other kernel sources (digest {d.get('source_digest')})"
+        return None, f"{os.path.relpath(path, ROOT)} was measured on other kernel sources (digest {d.get('source_digest')})"
     if d.get("workload") != workload:
-        return None, f"{os.path.relpath(PMC_FILE, ROOT)} holds workload {d.get('workload')}"
+        return None, f"{os.path.relpath(path, ROOT)} holds workload {d.get('workload')}"
+    d["_path"] = os.path.relpath(path, ROOT)
     return d, None
 
 
@@ -79,7 +85,7 @@ def pmc_for(pmc, short, pairs):
     if not k:
         return None
     scale = pairs / pmc["pairs"]
-    out = {"kernel_name": k["kernel_name"], "source": f"{os.path.relpath(PMC_FILE, ROOT)}@{pmc.get('git_head', '?')}"}
+    out = {"kernel_name": k["kernel_name"], "source": f"{pmc.get('_path', '?')}@{pmc.get('git_head', '?')}"}
     for key in ("traffic_bytes", "fetch_bytes", "write_bytes", "insts_valu", "active_inst_valu", "thread_cycles_valu"):
         if k.get(key) is not None:
             out[key] = k[key] * scale

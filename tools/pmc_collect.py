@@ -143,16 +143,17 @@ def main():
     ap.add_argument("--head", default="unknown", help="git HEAD of the tree being measured (the box has no .git)")
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--pairs", type=int, default=0, help="pairs per launch (default: the workload's batch capped at 1e6)")
     args = ap.parse_args()
     if args.remix:
-        with open(bench.PMC_FILE) as fh:
+        with open(bench.pmc_path(args.workload)) as fh:
             doc = json.load(fh)
         if doc.get("source_digest") != bench.kernel_source_digest():
             raise SystemExit("the kernel sources changed since the counters were collected: re-run on the GPU box")
         for k in ("cycles_per_inst_mix", "static_valu_instructions", "unlisted_ops_priced_as_generic_vop3", "note", "mix_kernel"):
             doc["ubench"].pop(k, None)
         add_mixes(doc["kernels"], doc["ubench"])
-        with open(bench.PMC_FILE, "w") as fh:
+        with open(bench.pmc_path(args.workload), "w") as fh:
             json.dump(doc, fh, indent=1)
         for short, e in doc["kernels"].items():
             print(short, e["kernel_name"], e.get("valu_mix", {}).get("cycles_per_inst_mix"))
@@ -160,13 +161,13 @@ def main():
     out_dir = os.path.join(ROOT, "gpurun_out", "final", "pmc")
     os.makedirs(out_dir, exist_ok=True)
     bench_args = ["--workload", args.workload, "--steps", str(args.steps), "--warmup", "1", "--no-cpu-baseline",
-                  "--no-sequential", "--no-standalone"]
+                  "--no-sequential", "--no-standalone"] + (["--pairs", str(args.pairs)] if args.pairs else [])
     data = {name: run_pass(name, ctrs, out_dir, bench_args) for name, ctrs in PASSES.items()}
 
     import approximate_string_matching_amd as asm
 
     _, n_default, _ = asm.workload(args.workload)
-    pairs = min(n_default, 1_000_000)
+    pairs = args.pairs or min(n_default, 1_000_000)
     kernels = {}
     for short, prefix in FAMILIES:
         # the family's kernel of the timed region = the one launched most often
@@ -210,11 +211,12 @@ def main():
                        "wide coalesced reads) + WRITE_SIZE KiB, per launch, mean over the launches of the run",
            "git_head": args.head, "source_digest": bench.kernel_source_digest(), "workload": args.workload, "pairs": pairs,
            "simd_count": 1024, "kernels": kernels, "ubench": ubench}
-    for path in (bench.PMC_FILE, os.path.join(ROOT, "gpurun_out", "final", os.path.basename(bench.PMC_FILE))):
+    target = bench.pmc_path(args.workload)
+    for path in (target, os.path.join(ROOT, "gpurun_out", "final", os.path.basename(target))):
         os.makedirs(os.path.dirname(path), exist_ok=True)
         with open(path, "w") as fh:
             json.dump(doc, fh, indent=1)
-    print("wrote", bench.PMC_FILE)
+    print("wrote", target)
 
 
 if __name__ == "__main__":
