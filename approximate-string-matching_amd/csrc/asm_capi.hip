@@ -52,6 +52,7 @@ struct asm_handle {
                                              wave per SIMD (ASM_PERSIST_WIDE=0: wave per pair) */
     bool group_kernels = true;            /* Greedy, 32 <= k <= 39: sixteen threads per pair (ASM_GROUP=0: two wavefronts per pair) */
     bool nw_banded = true;                /* banded bit-parallel NW with in-kernel full-height recompute (ASM_NW_BANDED=0) */
+    int leap_quad = 3;                    /* LEAP, wide band: four threads per pair (ASM_LEAP_QUAD bit 0: unit penalties, bit 1: general) */
     bool leap_band = true;                /* LEAP, wide band: thread per pair with the band in LDS (ASM_LEAP_BAND=0: wave per pair) */
     bool nw_wfa = true;                   /* affine NW: banded wavefront first, full matrix for the rest (ASM_NW_WFA=0: full matrix only) */
     std::vector<hipEvent_t> prof_ev;      /* asm_profile_enable: 8 events per recorded asm_run_benchmark_async call */
@@ -463,6 +464,7 @@ int asm_create(asm_handle** out, int device) {
     if ((env = getenv("ASM_NW_BANDED"))) h->nw_banded = env[0] != '0';
     if ((env = getenv("ASM_NW_WFA"))) h->nw_wfa = env[0] != '0';
     if ((env = getenv("ASM_LEAP_BAND"))) h->leap_band = env[0] != '0';
+    if ((env = getenv("ASM_LEAP_QUAD"))) h->leap_quad = atoi(env);
     if ((env = getenv("ASM_REFILL_GREEDY"))) h->refill_greedy = atoi(env);
     if ((env = getenv("ASM_REFILL_LEAP"))) h->refill_leap = atoi(env);
     *out = h;
@@ -1154,6 +1156,24 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
                 case 4: HIPCHK(h, launch_leap_general<4>(h, b, p, out)); break;
                 default: HIPCHK(h, launch_leap_general<5>(h, b, p, out)); break;
             }
+        } else if (h->wave_kernels && ((unit && (h->leap_quad & 1)) || (!unit && (h->leap_quad & 2))) && b.maxlen <= 512 &&
+                   leap_quad_lds((b.maxlen + 31) / 32, (int)p->k, unit ? 2 : RingGeometry(p->x, p->o, p->e).gm,
+                                 unit ? 0 : RingGeometry(p->x, p->o, p->e).gi, b.maxlen + 2 <= 255 ? 1 : 2) <= 64 * 1024) {
+            /* wide band: four threads per pair, generation rings and planes in LDS (asm_wave.h) */
+            const RingGeometry rg(p->x, p->o, p->e);
+            const int w32 = (b.maxlen + 31) / 32;
+#define LEAP_QUAD(W)                                                                                                          \
+    HIPCHK(h, (b.maxlen + 2 <= 255 ? launch_leap_quad<W, uint8_t>(h->stream, planes, lens, b.n, b.w4, (int)p->k, unit, (int)p->x, \
+                                                                  (int)p->o, (int)p->e, rg.gm, rg.gi, out)                      \
+                                   : launch_leap_quad<W, uint16_t>(h->stream, planes, lens, b.n, b.w4, (int)p->k, unit, (int)p->x, \
+                                                                   (int)p->o, (int)p->e, rg.gm, rg.gi, out)))
+            if (w32 <= 4) LEAP_QUAD(4);
+            else if (w32 <= 5) LEAP_QUAD(5);
+            else if (w32 <= 6) LEAP_QUAD(6);
+            else if (w32 <= 8) LEAP_QUAD(8);
+            else if (w32 <= 12) LEAP_QUAD(12);
+            else LEAP_QUAD(16);
+#undef LEAP_QUAD
         } else if (unit && h->leap_band && h->wave_kernels &&
                    leap_band_lds((b.maxlen + 31) / 32, (int)p->k, b.maxlen + 2 <= 255 ? 1 : 2) <= 64 * 1024) {
             /* wide band, unit penalties: thread per pair, band and planes in LDS (asm_wave.h) */

@@ -113,16 +113,16 @@ __global__ __launch_bounds__(ASM_BLOCK) void leap_wave_kernel(const uint4* __res
 // --------------------------------------------------------------------------------------------------------
 #define LEAP_BAND_THREADS 128
 
-template <int PD> /* plane dwords per string in LDS, one zero dword of padding included */
+template <int PD, int TS = LEAP_BAND_THREADS> /* PD plane dwords per string in LDS, one zero dword of padding included; TS = column stride */
 ASM_DEV uint32_t leap_band_window(const uint32_t* plane, int pos) {
     const int q = pos >> 5;
-    return __builtin_amdgcn_alignbit(plane[(q + 1) * LEAP_BAND_THREADS], plane[q * LEAP_BAND_THREADS], (uint32_t)(pos & 31));
+    return __builtin_amdgcn_alignbit(plane[(q + 1) * TS], plane[q * TS], (uint32_t)(pos & 31));
 }
 
 // first position p >= from at which lane d sees a mismatch (or either string has run out), as leap_lane_mask defines it
-template <int PD>
+template <int PD, int TS = LEAP_BAND_THREADS>
 ASM_DEV int leap_band_extend(const uint32_t* pl, int d, int from, int m, int nn) {
-    constexpr int PS = PD * LEAP_BAND_THREADS; /* dwords between planes */
+    constexpr int PS = PD * TS; /* dwords between planes */
     const int s = d < 0 ? -d : d;
     int lim = d < 0 ? m + s : nn + s; /* d < 0: A[p-s] against B[p]; d >= 0: A[p] against B[p-s] */
     const int other = d < 0 ? nn : m;
@@ -130,8 +130,8 @@ ASM_DEV int leap_band_extend(const uint32_t* pl, int d, int from, int m, int nn)
     if (from < s || from >= lim) return from;
     int apos = d < 0 ? from - s : from, bpos = d < 0 ? from : from - s, p = from;
     for (;;) {
-        const uint32_t diff = (leap_band_window<PD>(pl, apos) ^ leap_band_window<PD>(pl + 2 * PS, bpos)) |
-                              (leap_band_window<PD>(pl + PS, apos) ^ leap_band_window<PD>(pl + 3 * PS, bpos));
+        const uint32_t diff = (leap_band_window<PD, TS>(pl, apos) ^ leap_band_window<PD, TS>(pl + 2 * PS, bpos)) |
+                              (leap_band_window<PD, TS>(pl + PS, apos) ^ leap_band_window<PD, TS>(pl + 3 * PS, bpos));
         if (diff) {
             p += __builtin_ctz(diff);
             break;
@@ -354,6 +354,179 @@ static inline hipError_t launch_leap_band_general(hipStream_t stream, const uint
         if (e2 != hipSuccess) return e2;
     }
     hipLaunchKernelGGL((leap_band_general_kernel<W32, EnT>), grid, block, lds, stream, planes, lens, (long)n, w4, k, x, o, e, gm, gi, out);
+    return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------------------------------
+// LEAP, wide band, FOUR THREADS PER PAIR (a quad), sixteen pairs per wave.  Within one generation the lanes are independent —
+// `end`, I and D of generation e read generations e-o, e-x and e-ext only — so the live lanes of a pair are dealt round-robin to
+// the four threads of its quad (lane l goes to thread l mod 4: the live range is centred, every thread gets a quarter of it).
+// Against the thread-per-pair kernels above this divides the LDS a wave needs by four (rings and planes of 16 pairs instead
+// of 64), which is what bounds their occupancy: at k = 30 the (2,3,1) rings let three waves share a CU there and seventeen
+// here; a wave also waits for the slowest of 16 pairs rather than of 64.  Generations are kept in rings of thread-shared LDS
+// columns [slot][lane row][pair] (bytes or shorts, stored +2 so that 0 = "never reached"); with unit penalties two `end`
+// slots are enough (I and D are redundant at o == ext, see leap_unit_pair).  A wave's LDS operations complete in program
+// order, so the only synchronisation between generations is a wave-scope fence that keeps the compiler from moving a read
+// of another thread's value above the writes of the generation before.
+// Same recurrences and results as leap_band_kernel / leap_band_general_kernel (LV::run, LV_BAG.cpp:127-245).
+// --------------------------------------------------------------------------------------------------------
+#define LEAP_QUAD_THREADS 64
+#define LEAP_QUAD_PAIRS 16
+#define LEAP_QUAD_PSTRIDE 17 /* plane column stride in dwords: odd, so the dwords one quad reads fall into different banks */
+
+ASM_DEV void leap_quad_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+ASM_DEV int quad_or(int v) {
+    v |= __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false); /* quad_perm [1,0,3,2] */
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false); /* quad_perm [2,3,0,1] */
+    return v;
+}
+
+template <int W32, typename EnT, bool UNIT>
+__global__ __launch_bounds__(LEAP_QUAD_THREADS) void leap_quad_kernel(const uint4* __restrict__ planes,
+                                                                      const uint32_t* __restrict__ lens, long n, int w4, int k,
+                                                                      int x, int o, int ext, int gm, int gi, OutMap out) {
+    constexpr int P = LEAP_QUAD_PAIRS, TS = LEAP_QUAD_PSTRIDE, PD = W32 + 1;
+    extern __shared__ uint32_t s_band[];
+    const int t = threadIdx.x, pr = t >> 2, q = t & 3;
+    const int rows = 2 * k + 3; /* lane l at row l+1, guard rows 0 and 2k+2 */
+    const int slot = rows * P;  /* elements per ring slot */
+    uint32_t* const pl = s_band + pr;                                          /* [4][PD][TS] */
+    EnT* const r_en = reinterpret_cast<EnT*>(s_band + 4 * PD * TS) + pr;      /* [gm][rows][P] */
+    EnT* const r_ip = r_en + gm * slot;                                        /* [gi][rows][P] (general penalties only) */
+    EnT* const r_dp = r_ip + gi * slot;
+    {
+        const int words = (int)(((size_t)(gm + 2 * gi) * slot * sizeof(EnT) + 3) / 4);
+        uint32_t* const base = s_band + 4 * PD * TS;
+        for (int w = t; w < words; w += LEAP_QUAD_THREADS) base[w] = 0u;
+    }
+    const long i = (long)blockIdx.x * P + pr;
+    const bool live = i < n;
+    int m = 0, nn = 0;
+    if (live) { /* thread q of the quad stages plane q: read plane 0/1, reference plane 0/1 */
+        const uint32_t ln = lens[i];
+        m = (int)(ln & 0xffffu), nn = (int)(ln >> 16);
+#pragma unroll
+        for (int g = 0; g < (W32 + 3) / 4; g++) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (g < w4) v = planes[((long)q * w4 + g) * n + i];
+            uint32_t* dst = pl + (q * PD + 4 * g) * TS;
+            dst[0] = v.x;
+            if (4 * g + 1 < W32) dst[TS] = v.y;
+            if (4 * g + 2 < W32) dst[2 * TS] = v.z;
+            if (4 * g + 3 < W32) dst[3 * TS] = v.w;
+        }
+        pl[(q * PD + W32) * TS] = 0u;
+    }
+    const int len = m > nn ? m : nn; /* benchmark_utils.h:162 */
+    leap_quad_fence();
+    int result = live ? -1 : 0;
+    if (live) { /* e = 0: main diagonal only (LV_BAG.cpp:102-104,131-147); the four threads compute the same value */
+        int e0 = leap_band_extend<PD, TS>(pl, 0, 0, m, nn);
+        e0 = e0 > len ? len : e0;
+        if (q == 0) r_en[(k + 1) * P] = (EnT)(e0 + 2);
+        if (e0 == len) result = 0;
+    }
+    leap_quad_fence();
+    for (int e = 1; e <= ASM_LEAP_AF_THRESHOLD; e++) {
+        if (__ballot(result < 0) == 0ull) break;
+        int pass = 0;
+        if (result < 0) {
+            if constexpr (UNIT) {
+                const int lo = k - e > 0 ? k - e : 0, hi = k + e < 2 * k ? k + e : 2 * k;
+                const EnT* const en_r = r_en + ((e - 1) & 1) * slot;
+                EnT* const en_w = r_en + (e & 1) * slot;
+                for (int l = lo + q; l <= hi; l += 4) {
+                    const int up_old = (int)en_r[l * P] - 2, cur_old = (int)en_r[(l + 1) * P] - 2, dn_old = (int)en_r[(l + 2) * P] - 2;
+                    const int d = l - k;
+                    const int top = d >= 0 ? 1 : 0, bot = d <= 0 ? 1 : 0;
+                    int st = cur_old + 1;                         /* LV_BAG.cpp:186-187 */
+                    st = up_old + top > st ? up_old + top : st;   /* I_pos (redundant table at o = ext, see leap_unit_pair) */
+                    st = dn_old + bot > st ? dn_old + bot : st;   /* D_pos */
+                    int enew = -2;
+                    if (st >= 0) {
+                        const int from = st > len ? len : st;
+                        int r = leap_band_extend<PD, TS>(pl, d, from, m, nn); /* count_ID_length, :9-23 */
+                        r = r > len ? len : r;
+                        enew = st > len ? st : r;
+                        const int diff = d < 0 ? -d : d;
+                        if (enew == len && e + diff <= ASM_LEAP_AF_THRESHOLD) pass = 1; /* :220-238 */
+                    }
+                    en_w[(l + 1) * P] = (EnT)(enew + 2);
+                }
+            } else {
+                int dmax = e < o ? 0 : (e - o) / ext + 1;
+                dmax = dmax > k ? k : dmax;
+                const EnT* const en_o = r_en + ((e - o) & (gm - 1)) * slot;
+                const EnT* const en_x = r_en + ((e - x) & (gm - 1)) * slot;
+                const EnT* const ip_e = r_ip + ((e - ext) & (gi - 1)) * slot;
+                const EnT* const dp_e = r_dp + ((e - ext) & (gi - 1)) * slot;
+                EnT* const en_w = r_en + (e & (gm - 1)) * slot;
+                EnT* const ip_w = r_ip + (e & (gi - 1)) * slot;
+                EnT* const dp_w = r_dp + (e & (gi - 1)) * slot;
+                const bool has_o = e >= o, has_e = e >= ext, has_x = e >= x;
+                for (int l = k - dmax + q; l <= k + dmax; l += 4) {
+                    const int d = l - k;
+                    const int top = d >= 0 ? 1 : 0, bot = d <= 0 ? 1 : 0;
+                    const int e_up = has_o ? (int)en_o[l * P] - 2 : -2;       /* lane l-1 sits at row l */
+                    const int i_up = has_e ? (int)ip_e[l * P] - 2 : -2;
+                    const int e_dn = has_o ? (int)en_o[(l + 2) * P] - 2 : -2; /* lane l+1 */
+                    const int d_dn = has_e ? (int)dp_e[(l + 2) * P] - 2 : -2;
+                    const int own = has_x ? (int)en_x[(l + 1) * P] - 2 : -2;
+                    int inew = -2, dnew = -2;
+                    if (e_up >= 0 && e_up > i_up)
+                        inew = e_up + top; /* LV_BAG.cpp:166-167 */
+                    else if (i_up >= 0)
+                        inew = i_up + top; /* :172-176 */
+                    if (e_dn >= 0 && e_dn > d_dn)
+                        dnew = e_dn + bot; /* :179-180 */
+                    else if (d_dn >= 0)
+                        dnew = d_dn + bot; /* :181-182 */
+                    int st = own >= 0 ? own + 1 : -2; /* :186-187 */
+                    st = inew > st ? inew : st;
+                    st = dnew > st ? dnew : st;
+                    int enew = -2;
+                    if (st >= 0) {
+                        const int from = st > len ? len : st;
+                        int r = leap_band_extend<PD, TS>(pl, d, from, m, nn); /* count_ID_length, :9-23 */
+                        r = r > len ? len : r;
+                        enew = st > len ? st : r;
+                        if (enew == len) { /* :220-238 */
+                            const int diff = d < 0 ? -d : d;
+                            const int conv = e + (diff ? o + (diff - 1) * ext : 0);
+                            if (conv <= ASM_LEAP_AF_THRESHOLD) pass = 1;
+                        }
+                    }
+                    en_w[(l + 1) * P] = (EnT)(enew + 2), ip_w[(l + 1) * P] = (EnT)(inew + 2), dp_w[(l + 1) * P] = (EnT)(dnew + 2);
+                }
+            }
+        }
+        pass = quad_or(pass);
+        if (pass && result < 0) result = e; /* final_ED (LV_BAG.cpp:228,356-358) */
+        leap_quad_fence();
+    }
+    if (live && q == 0) out.put(i, result);
+}
+
+static inline size_t leap_quad_lds(int w32, int k, int gm, int gi, size_t en_bytes) {
+    return (size_t)4 * (w32 + 1) * LEAP_QUAD_PSTRIDE * sizeof(uint32_t) +
+           (((size_t)(gm + 2 * gi) * (2 * k + 3) * LEAP_QUAD_PAIRS * en_bytes + 3) & ~(size_t)3);
+}
+
+template <int W32, typename EnT>
+static inline hipError_t launch_leap_quad(hipStream_t stream, const uint4* planes, const uint32_t* lens, int64_t n, int w4, int k,
+                                          bool unit, int x, int o, int e, int gm, int gi, OutMap out) {
+    const dim3 grid((unsigned)((n + LEAP_QUAD_PAIRS - 1) / LEAP_QUAD_PAIRS)), block(LEAP_QUAD_THREADS);
+    if (unit) {
+        hipLaunchKernelGGL((leap_quad_kernel<W32, EnT, true>), grid, block, leap_quad_lds(W32, k, 2, 0, sizeof(EnT)), stream, planes,
+                           lens, (long)n, w4, k, 1, 1, 1, 2, 0, out);
+    } else {
+        hipLaunchKernelGGL((leap_quad_kernel<W32, EnT, false>), grid, block, leap_quad_lds(W32, k, gm, gi, sizeof(EnT)), stream,
+                           planes, lens, (long)n, w4, k, x, o, e, gm, gi, out);
+    }
     return hipGetLastError();
 }
 

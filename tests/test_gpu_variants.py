@@ -1,6 +1,6 @@
 """Every kernel family stays parity-green, not only the default dispatch: the A/B switches of the C-ABI library
 (environment variables read at asm_create) select the alternative kernels — one-pair-per-thread Greedy, lane-refilling
-LEAP, unsorted LEAP, full-height NW, workgroup-per-pair and wave-per-pair wide kernels, unbucketed batches — and each is checked against the
+LEAP, unsorted LEAP, full-height NW, thread-per-pair, workgroup-per-pair and wave-per-pair wide kernels, unbucketed batches — and each is checked against the
 oracle in a fresh process."""
 import os
 import subprocess
@@ -55,7 +55,8 @@ print("ok")
     {"ASM_LEAP_HINT": "0"},
     {"ASM_NW_BANDED": "0", "ASM_NW_WFA": "0"},
     {"ASM_WAVE": "0"},
-    {"ASM_LEAP_BAND": "0"},
+    {"ASM_LEAP_QUAD": "0"},
+    {"ASM_LEAP_QUAD": "0", "ASM_LEAP_BAND": "0"},
     {"ASM_BUCKET": "0"},
     {"ASM_REFILL_GREEDY": "1", "ASM_REFILL_LEAP": "64", "ASM_PERSIST_LEAP": "1", "ASM_LEAP_HINT": "0"},
 ])
