@@ -35,6 +35,7 @@ struct asm_handle {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    unsigned long long* d_pair_queue = nullptr; /* chunk counter of the wave-per-pair Greedy kernel (PairQueue, asm_wave.h) */
     hipStream_t side_stream = nullptr;    /* asm_run_benchmark_async runs Greedy beside the NW -> LEAP chain */
     hipStream_t pack_stream = nullptr;    /* ... and, with repack = 2, packs for this call while the previous call still aligns */
     hipEvent_t ev_packed = nullptr;
@@ -444,6 +445,7 @@ int asm_create(asm_handle** out, int device) {
     HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
     HIPCHK(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+    HIPCHK(h, hipMalloc((void**)&h->d_pair_queue, sizeof(unsigned long long)));
     HIPCHK(h, hipStreamCreateWithFlags(&h->pack_stream, hipStreamNonBlocking));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_packed, hipEventDisableTiming));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -476,6 +478,7 @@ int asm_destroy(asm_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+    if (h->d_pair_queue) (void)hipFree(h->d_pair_queue);
     if (h->pack_stream) (void)hipStreamDestroy(h->pack_stream);
     if (h->ev_packed) (void)hipEventDestroy(h->ev_packed);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -1125,13 +1128,15 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
                     /* 65..79 band lanes: sixteen threads per pair, five lanes each (asm_group.h): 1.78 ms per 10^6 C2 pairs
                      * against 2.25 ms for the two-wavefront kernel */
                     HIPCHK(h, launch_greedy_group(h->stream, planes, lens, b.n, b.w4, (int)p->k, ga, out, cig, h->num_cus));
-                } else if (p->k <= ASM_WAVE_MAX_K && h->wave_kernels && unit && !ga.semi)
+                } else if (p->k <= ASM_WAVE_MAX_K && h->wave_kernels && unit && !ga.semi) {
+                    HIPCHK(h, hipMemsetAsync(h->d_pair_queue, 0, sizeof(unsigned long long), h->stream));
                     launch_wave_per_pair(h->stream, greedy_wave_kernel<true>, b.n, h->num_cus, planes, lens, (long)b.n, b.w4,
-                                         (int)p->k, ga, out, cig);
-                else if (p->k <= ASM_WAVE_MAX_K && h->wave_kernels && (long)p->o + 62L * p->e < 16000L)
+                                         (int)p->k, ga, out, cig, h->d_pair_queue);
+                } else if (p->k <= ASM_WAVE_MAX_K && h->wave_kernels && (long)p->o + 62L * p->e < 16000L) {
+                    HIPCHK(h, hipMemsetAsync(h->d_pair_queue, 0, sizeof(unsigned long long), h->stream));
                     launch_wave_per_pair(h->stream, greedy_wave_kernel<false>, b.n, h->num_cus, planes, lens, (long)b.n, b.w4,
-                                         (int)p->k, ga, out, cig);
-                else if (h->wave_kernels && (long)p->o + 100L * p->e < 16000L)
+                                         (int)p->k, ga, out, cig, h->d_pair_queue);
+                } else if (h->wave_kernels && (long)p->o + 100L * p->e < 16000L)
                     launch_greedy_wave2(h->stream, planes, lens, b.n, b.w4, (int)p->k, ga, out, cig, h->num_cus);
                 else
                     launch_greedy_wide(h->stream, planes, lens, b.n, b.w4, p->k, ga, out, cig);

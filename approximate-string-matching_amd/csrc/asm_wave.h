@@ -102,6 +102,34 @@ __global__ __launch_bounds__(ASM_BLOCK) void leap_wave_kernel(const uint4* __res
 }
 
 // --------------------------------------------------------------------------------------------------------
+// Work distribution of the wave-per-pair kernels.  Their grid is sized to what is resident when the kernel runs alone; in
+// asm_run_benchmark_async they run beside another aligner's kernel and only part of the grid is resident at first, so a
+// static "wave w takes pairs w, w + W, ..." split leaves the late workgroups a full share to do after everybody else has
+// finished.  Each wave therefore draws chunks of PAIR_QUEUE_CHUNK consecutive pairs from a counter in device memory (zeroed
+// by the launcher on the same stream): one atomic per chunk, far below the rate a single address sustains.
+// --------------------------------------------------------------------------------------------------------
+#define PAIR_QUEUE_CHUNK 16
+struct PairQueue {
+    long chunk_end;
+    ASM_DEV long grab(unsigned long long* queue) {
+        unsigned long long b = 0;
+        if ((threadIdx.x & 63) == 0) b = atomicAdd(queue, (unsigned long long)PAIR_QUEUE_CHUNK);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+        return (long)(((unsigned long long)hi << 32) | lo);
+    }
+    ASM_DEV long first(unsigned long long* queue, long n) {
+        const long b = grab(queue);
+        chunk_end = b + PAIR_QUEUE_CHUNK;
+        return b < n ? b : n;
+    }
+    ASM_DEV long next(unsigned long long* queue, long i, long n) {
+        if (i + 1 < chunk_end) return i + 1;
+        return first(queue, n);
+    }
+};
+
+// --------------------------------------------------------------------------------------------------------
 // LEAP, unit penalties, wide band, ONE THREAD PER PAIR with the band in LDS.  In generation e only the lanes |d| <= e can
 // be live, so a wave-per-pair mapping keeps a third of its lanes busy at k = 30 (final_ED ~ 20); here a thread sweeps
 // exactly the live lanes of its own pair.  The lane's `end` values (one int16 per lane, updated in place: the sweep
@@ -537,16 +565,16 @@ static inline hipError_t launch_leap_quad(hipStream_t stream, const uint4* plane
 template <bool UNIT> /* UNIT: x = o = e = 1 at compile time */
 __global__ __launch_bounds__(ASM_BLOCK) void greedy_wave_kernel(const uint4* __restrict__ planes,
                                                                 const uint32_t* __restrict__ lens, long n, int w4,
-                                                                int k, GreedyArgs args, OutMap out, CigarSink cig) {
+                                                                int k, GreedyArgs args, OutMap out, CigarSink cig,
+                                                                unsigned long long* __restrict__ queue) {
     const int t = threadIdx.x & 63;
-    const long wave0 = __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
     const int nl = 2 * k + 1;
     const bool active = t < nl;
     const int lane = t - k;
     const int x = UNIT ? 1 : args.x, o = UNIT ? 1 : args.o, e = UNIT ? 1 : args.e;
     const bool semi = UNIT ? false : args.semi != 0;
-    for (long i = wave0; i < n; i += nwaves) {
+    PairQueue pq;
+    for (long i = pq.first(queue, n); i < n; i = pq.next(queue, i, n)) {
         const V128 A0 = v_from_uint4(planes[((long)0 * w4) * n + i]);
         const V128 A1 = v_from_uint4(planes[((long)1 * w4) * n + i]);
         const V128 B0 = v_from_uint4(planes[((long)2 * w4) * n + i]);
