@@ -45,6 +45,7 @@ struct asm_handle {
     int num_cus = 256;
     bool persist = true;                  /* Greedy: lane-refilling persistent kernel (ASM_PERSIST=0 disables) */
     bool persist_leap = false;            /* LEAP: the plain one-pair-per-thread kernel is faster at 1e6 pairs (ASM_PERSIST_LEAP=1) */
+    int queue_dyn_permille = 0, queue_chunk = 128; /* persistent Greedy: share of the pairs handed out dynamically and pairs per draw (ASM_QUEUE_DYN, ASM_QUEUE_CHUNK); off — at C2 a wave's slice is 326 pairs and the draws of 3072 waves queue up on the counter: 0.153 -> 0.174 ms in the timed region at 500/128 */
     int refill_greedy = 8, refill_leap = 16; /* lanes that must be idle before a wave refills (tunable by env) */
     bool leap_hint = true;                /* LEAP scheduled by a work hint when one is given (ASM_LEAP_HINT=0 disables) */
     bool bucketing = true;                /* group mixed-length batches by width class (ASM_BUCKET=0 disables) */
@@ -55,6 +56,8 @@ struct asm_handle {
     bool nw_banded = true;                /* banded bit-parallel NW with in-kernel full-height recompute (ASM_NW_BANDED=0) */
     int leap_quad = 3;                    /* LEAP, wide band: four threads per pair (ASM_LEAP_QUAD bit 0: unit penalties, bit 1: general) */
     bool leap_band = true;                /* LEAP, wide band: thread per pair with the band in LDS (ASM_LEAP_BAND=0: wave per pair) */
+    int ring_bytes = -1;                  /* thread-per-pair generation rings as bytes: -1 = where it pays, 0 / 1 force (ASM_RING_BYTES) */
+    bool nw_wfa_second = true;            /* affine NW: second wavefront pass with the wider band (ASM_NW_WFA2=0: straight to the full matrix) */
     bool nw_wfa = true;                   /* affine NW: banded wavefront first, full matrix for the rest (ASM_NW_WFA=0: full matrix only) */
     std::vector<hipEvent_t> prof_ev;      /* asm_profile_enable: 8 events per recorded asm_run_benchmark_async call */
     std::vector<unsigned> prof_mask;      /* which of a call's four kernels were launched */
@@ -218,12 +221,18 @@ static hipError_t launch_greedy(asm_handle* h, const asm_bucket& b, const Greedy
 #ifdef GREEDY_DIAG
     if (cig.ops == nullptr && g_diag_buf) cig.nops = (uint8_t*)g_diag_buf;
 #endif
+    QueueArgs qa{nullptr, 0, 0};
+    if (h->persist && h->queue_dyn_permille > 0 && h->queue_chunk > 0) {
+        qa = QueueArgs{h->d_pair_queue, h->queue_dyn_permille, h->queue_chunk};
+        const hipError_t e = hipMemsetAsync(h->d_pair_queue, 0, sizeof(unsigned long long), h->stream);
+        if (e != hipSuccess) return e;
+    }
     if (h->persist && ga.x == 1 && ga.o == 1 && ga.e == 1 && !ga.semi)
         return launch_persistent(h, greedy_persist_kernel<K, true>, b.n, (const uint4*)b.planes, (const uint32_t*)b.lens,
-                                 (long)b.n, b.w4, ga, out, cig, h->refill_greedy);
+                                 (long)b.n, b.w4, ga, out, cig, h->refill_greedy, qa);
     if (h->persist)
         return launch_persistent(h, greedy_persist_kernel<K, false>, b.n, (const uint4*)b.planes, (const uint32_t*)b.lens,
-                                 (long)b.n, b.w4, ga, out, cig, h->refill_greedy);
+                                 (long)b.n, b.w4, ga, out, cig, h->refill_greedy, qa);
     if constexpr (K <= 5) { /* the one-pair-per-thread A/B form (ASM_PERSIST=0) exists for the narrow bands only */
         hipLaunchKernelGGL(greedy_kernel<K>, dim3(grid_for(b.n)), dim3(ASM_BLOCK), 0, h->stream, b.planes, b.lens, (long)b.n,
                            b.w4, ga, out, cig);
@@ -252,29 +261,59 @@ template <int K, int W64>
 static hipError_t launch_leap_general_w(asm_handle* h, const asm_bucket& b, const asm_params* p, OutMap out) {
     const dim3 grid((unsigned)((b.n + LEAP_GEN_THREADS - 1) / LEAP_GEN_THREADS)), block(LEAP_GEN_THREADS);
     const RingGeometry rg(p->x, p->o, p->e);
-    hipLaunchKernelGGL((leap_general_kernel<K, W64>), grid, block, rg.lds_bytes(2 * K + 1, LEAP_GEN_THREADS), h->stream,
-                       b.planes, b.lens, (long)b.n, b.w4, (int)p->x, (int)p->o, (int)p->e, rg.gm, rg.gi, out);
+    /* bytes (every stored position + 2 fits) halve the LDS and double the waves per CU, but four threads then write into one
+     * dword: worth it only where shorts would leave the CU underfilled */
+    const bool bytes = b.maxlen + 4 <= 255 && (h->ring_bytes < 0 ? rg.lds_bytes(2 * K + 1, LEAP_GEN_THREADS, 2) > 20 * 1024 : h->ring_bytes != 0);
+    if (bytes)
+        hipLaunchKernelGGL((leap_general_kernel<K, W64, uint8_t>), grid, block, rg.lds_bytes(2 * K + 1, LEAP_GEN_THREADS, 1), h->stream,
+                           b.planes, b.lens, (long)b.n, b.w4, (int)p->x, (int)p->o, (int)p->e, rg.gm, rg.gi, out);
+    else
+        hipLaunchKernelGGL((leap_general_kernel<K, W64, uint16_t>), grid, block, rg.lds_bytes(2 * K + 1, LEAP_GEN_THREADS, 2), h->stream,
+                           b.planes, b.lens, (long)b.n, b.w4, (int)p->x, (int)p->o, (int)p->e, rg.gm, rg.gi, out);
     return hipGetLastError();
 }
 
-/* Affine NW: banded wavefront pass, then the full-matrix kernel over the pairs the band could not settle. */
+/* Affine NW: banded wavefront pass (|d| <= 7), a second one with |d| <= 15 over the pairs the first could not settle
+ * (strings up to 128 only), then the full-matrix kernel over what is left.  Two todo lists of n + 1 words each. */
+template <int K, int W64, typename EnT, bool LISTED>
+static void launch_nw_wfa_pass(asm_handle* h, const asm_bucket& b, const asm_params* p, OutMap out, const uint32_t* in_list,
+                               const uint32_t* in_count, uint32_t* todo, uint32_t* todo_count) {
+    const WfaRings rg(p->x, p->o, p->e);
+    const dim3 grid((unsigned)((b.n + LEAP_GEN_THREADS - 1) / LEAP_GEN_THREADS)), block(LEAP_GEN_THREADS);
+    hipLaunchKernelGGL((nw_wfa_kernel<K, W64, EnT, LISTED>), grid, block, rg.lds_bytes(2 * K + 1, LEAP_GEN_THREADS, sizeof(EnT)),
+                       h->stream, b.planes, b.lens, (long)b.n, b.w4, (int)p->x, (int)p->o, (int)p->e, rg.gm, rg.gi, out, in_list,
+                       in_count, todo, todo_count);
+}
+
 template <int W64, int MAXROWS>
 static int launch_nw_wfa(asm_handle* h, const asm_bucket& b, const asm_params* p, OutMap out) {
-    if (h->todo_cap < (size_t)b.n + 1) {
+    const size_t words = 2 * ((size_t)b.n + 1);
+    if (h->todo_cap < words) {
         if (h->d_todo) (void)hipFree(h->d_todo);
         h->d_todo = nullptr, h->todo_cap = 0;
-        HIPCHK(h, hipMalloc((void**)&h->d_todo, sizeof(uint32_t) * ((size_t)b.n + 1)));
-        h->todo_cap = (size_t)b.n + 1;
+        HIPCHK(h, hipMalloc((void**)&h->d_todo, sizeof(uint32_t) * words));
+        h->todo_cap = words;
     }
-    HIPCHK(h, hipMemsetAsync(h->d_todo, 0, sizeof(uint32_t), h->stream));
-    const RingGeometry rg(p->x, p->o, p->e);
-    const dim3 grid((unsigned)((b.n + LEAP_GEN_THREADS - 1) / LEAP_GEN_THREADS)), block(LEAP_GEN_THREADS);
-    hipLaunchKernelGGL((nw_wfa_kernel<NW_WFA_K, W64>), grid, block, rg.lds_bytes(2 * NW_WFA_K + 1, LEAP_GEN_THREADS), h->stream,
-                       b.planes, b.lens, (long)b.n, b.w4, (int)p->x, (int)p->o, (int)p->e, rg.gm, rg.gi, out, h->d_todo + 1,
-                       h->d_todo);
+    uint32_t* const list_a = h->d_todo;                 /* [0] = count, [1..] = pair slots */
+    uint32_t* const list_b = h->d_todo + (size_t)b.n + 1;
+    HIPCHK(h, hipMemsetAsync(list_a, 0, sizeof(uint32_t), h->stream));
+    HIPCHK(h, hipMemsetAsync(list_b, 0, sizeof(uint32_t), h->stream));
+    const WfaRings rg(p->x, p->o, p->e);
+    bool bytes = false; /* strings up to 128: every stored position + 2 fits a byte, half the LDS */
+    if constexpr (W64 == 2) {
+        bytes = h->ring_bytes != 0;
+        if (bytes) launch_nw_wfa_pass<NW_WFA_K, 2, uint8_t, false>(h, b, p, out, nullptr, nullptr, list_a + 1, list_a);
+    }
+    if (!bytes) launch_nw_wfa_pass<NW_WFA_K, W64, uint16_t, false>(h, b, p, out, nullptr, nullptr, list_a + 1, list_a);
+    const uint32_t* rest = list_a;
+    if constexpr (W64 == 2) {
+        if (h->nw_wfa_second && rg.lds_bytes(2 * NW_WFA_K2 + 1, LEAP_GEN_THREADS, 1) <= 64 * 1024) {
+            launch_nw_wfa_pass<NW_WFA_K2, 2, uint8_t, true>(h, b, p, out, list_a + 1, list_a, list_b + 1, list_b);
+            rest = list_b;
+        }
+    }
     hipLaunchKernelGGL((nw_affine_kernel<W64, MAXROWS>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 0, h->stream, b.planes,
-                       b.lens, (long)b.n, b.w4, (int)p->x, (int)p->o, (int)p->e, out, (const uint32_t*)(h->d_todo + 1),
-                       (const uint32_t*)h->d_todo);
+                       b.lens, (long)b.n, b.w4, (int)p->x, (int)p->o, (int)p->e, out, rest + 1, rest);
     HIPCHK(h, hipGetLastError());
     return ASM_OK;
 }
@@ -465,9 +504,13 @@ int asm_create(asm_handle** out, int device) {
     if ((env = getenv("ASM_PERSIST_WIDE"))) h->persist_wide = env[0] != '0';
     if ((env = getenv("ASM_NW_BANDED"))) h->nw_banded = env[0] != '0';
     if ((env = getenv("ASM_NW_WFA"))) h->nw_wfa = env[0] != '0';
+    if ((env = getenv("ASM_NW_WFA2"))) h->nw_wfa_second = env[0] != '0';
+    if ((env = getenv("ASM_RING_BYTES"))) h->ring_bytes = atoi(env);
     if ((env = getenv("ASM_LEAP_BAND"))) h->leap_band = env[0] != '0';
     if ((env = getenv("ASM_LEAP_QUAD"))) h->leap_quad = atoi(env);
     if ((env = getenv("ASM_REFILL_GREEDY"))) h->refill_greedy = atoi(env);
+    if ((env = getenv("ASM_QUEUE_DYN"))) h->queue_dyn_permille = atoi(env) < 0 ? 0 : (atoi(env) > 1000 ? 1000 : atoi(env));
+    if ((env = getenv("ASM_QUEUE_CHUNK"))) h->queue_chunk = atoi(env) < 1 ? 1 : atoi(env);
     if ((env = getenv("ASM_REFILL_LEAP"))) h->refill_leap = atoi(env);
     *out = h;
     return ASM_OK;
@@ -1246,10 +1289,10 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
             else
                 hipLaunchKernelGGL((nw_banded_kernel<16, 64>), g, t, 0, h->stream, planes, lens, n, b.w4, out);
         } else {
-            const RingGeometry rg(p->x, p->o, p->e);
             /* a zero penalty makes the wavefront read the generation it is writing (ring slot s - 0): plain Gotoh handles it */
             const bool positive = p->x >= 1 && p->o >= 1 && p->e >= 1;
-            if (h->nw_wfa && positive && b.maxlen <= 256 && rg.lds_bytes(2 * NW_WFA_K + 1, LEAP_GEN_THREADS) <= 64 * 1024) {
+            if (h->nw_wfa && positive && b.maxlen <= 256 &&
+                WfaRings(p->x, p->o, p->e).lds_bytes(2 * NW_WFA_K + 1, LEAP_GEN_THREADS, 2) <= 64 * 1024) {
                 const int rc = b.maxlen <= 128 ? launch_nw_wfa<2, 128>(h, b, p, out) : launch_nw_wfa<4, 256>(h, b, p, out);
                 if (rc != ASM_OK) return rc;
             } else {

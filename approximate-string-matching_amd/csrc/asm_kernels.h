@@ -419,21 +419,51 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_kernel(const uint4* __restri
 // (static split over the resident waves: ~n/3000 pairs each, so slices are balanced to a few percent) and its lanes pull
 // the next pair with wave-level bit tricks only — no memory atomics (a single global queue head saturates at ~88
 // dequeues/us on this chip, far below the refill rate of these kernels).
+// The static split leaves two things on the table: slices differ in total work (a few percent of standard deviation, and
+// the kernel lasts as long as its slowest wave), and when the kernel runs beside another one only part of its grid is
+// resident at first.  So the split covers the first (1000 - dyn_permille)/1000 of the pairs only, and a wave whose slice
+// is used up draws chunks of `chunk` pairs of the rest from a counter in device memory (zeroed by the launcher) — a few
+// thousand atomics per launch, well below that rate.
+struct QueueArgs {
+    unsigned long long* counter; /* nullptr: static split of everything */
+    int dyn_permille, chunk;
+};
 struct WaveQueue {
-    long next, end;
-    ASM_DEV void init(long n) {
+    long next, end, pool_lo, pool_hi;
+    unsigned long long* counter;
+    int chunk;
+    bool dry;
+    ASM_DEV void init(long n, QueueArgs qa = QueueArgs{nullptr, 0, 0}) {
         const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
         const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
-        next = n * wave / nwaves;
-        end = n * (wave + 1) / nwaves;
+        const long n_dyn = (qa.counter && qa.chunk > 0) ? n * qa.dyn_permille / 1000 : 0;
+        const long n_static = n - n_dyn;
+        next = n_static * wave / nwaves;
+        end = n_static * (wave + 1) / nwaves;
+        pool_lo = n_static, pool_hi = n;
+        counter = qa.counter, chunk = qa.chunk;
+        dry = n_dyn == 0;
     }
-    // lanes with need=true receive consecutive indices; returns -1 when the slice is used up
+    // lanes with need=true receive consecutive indices; returns -1 when everything is used up and -2 for "nothing this
+    // time, ask again" (the slice ran out in the middle of a refill and the pool has not been asked yet)
     ASM_DEV long pull(bool need) {
         const unsigned long long mask = __ballot(need);
         const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
         const long cnt = (long)__popcll(mask);
+        if (next >= end && !dry) { /* wave-uniform */
+            unsigned long long b = 0;
+            if ((threadIdx.x & 63) == 0) b = atomicAdd(counter, (unsigned long long)chunk);
+            const long base = pool_lo + (long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b) +
+                              ((long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32)) << 32);
+            if (base >= pool_hi) {
+                dry = true;
+            } else {
+                next = base;
+                end = base + chunk < pool_hi ? base + chunk : pool_hi;
+            }
+        }
         const long avail = end - next;
-        const long idx = (need && rank < avail) ? next + rank : -1;
+        const long idx = need ? (rank < avail ? next + rank : (dry ? -1 : -2)) : -1;
         next += cnt < avail ? cnt : avail;
         return idx;
     }
@@ -450,7 +480,7 @@ template <int K, bool UNIT> /* UNIT: x = o = e = 1 known at compile time (the be
 __global__ __launch_bounds__(ASM_BLOCK) void greedy_persist_kernel(const uint4* __restrict__ planes,
                                                                    const uint32_t* __restrict__ lens, long n, int w4,
                                                                    GreedyArgs args, OutMap out,
-                                                                   CigarSink cig, int refill_min) {
+                                                                   CigarSink cig, int refill_min, QueueArgs qa) {
     constexpr int NL = 2 * K + 1;
 #ifndef ASM_PERSIST_KEEP_LF
 #define ASM_PERSIST_KEEP_LF 5 /* largest K whose flipped lane vectors stay in registers; above it they are rebuilt per look-up */
@@ -466,7 +496,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_persist_kernel(const uint4* 
     long idx = -1, pair = 0;
     bool active = false, finished = true, exhausted = false;
     WaveQueue wq;
-    wq.init(n);
+    wq.init(n, qa);
 #pragma unroll
     for (int j = 0; j < NL; j++) {
         lo_[j] = v_make(0, 0);
@@ -502,7 +532,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_persist_kernel(const uint4* 
             if (need) {
                 idx = got;
                 active = got >= 0;
-                exhausted = !active;
+                exhausted = got == -1; /* -2: the lane stays idle and asks again at the next refill */
             }
             if (need && active) {
                 const V128 A0 = v_from_uint4(planes[((long)0 * w4) * n + idx]);
@@ -852,8 +882,8 @@ __global__ __launch_bounds__(ASM_BLOCK) void leap_unit_hint_kernel(const uint4* 
 // e-x (end) and e-ext (I, D) (LV_BAG.cpp:166-187), so rings of GM = 2^a > max(x, o) generations of `end` and
 // GI = 2^b > ext generations of I and D are kept — per thread, as int16 (positions <= 512), in dynamic LDS laid out
 // [ring][slot][lane][thread]: thread-private columns, so no barriers and no bank conflicts; slot offsets are wave-uniform
-// (scalar).  Every slot read in generation e was written earlier for THIS pair (the e >= penalty guards of the
-// reference), so the rings need no clearing between pairs.
+// (scalar).  All slots are filled with "never reached" before generation 0, which also stands in for the e >= penalty guards
+// of the reference (see the loop).
 // --------------------------------------------------------------------------------------------------------
 #define LEAP_GEN_THREADS 128
 struct RingGeometry { /* power-of-two ring depths for (x, o, e) and the LDS bytes a block of T threads with NL lanes needs */
@@ -864,19 +894,19 @@ struct RingGeometry { /* power-of-two ring depths for (x, o, e) and the LDS byte
         return g;
     }
     __host__ RingGeometry(int x, int o, int e) : gm(pow2_above(x > o ? x : o)), gi(pow2_above(e)) {}
-    __host__ size_t lds_bytes(int nl, int threads) const { return (size_t)(gm + 2 * gi) * nl * threads * sizeof(short); }
+    __host__ size_t lds_bytes(int nl, int threads, size_t elem = sizeof(short)) const { return ((size_t)(gm + 2 * gi) * nl * threads * elem + 3) & ~(size_t)3; }
 };
 
-template <int K, int W64>
+template <int K, int W64, typename EnT> /* EnT: ring element, values stored + 2 (0 = never reached) */
 __global__ __launch_bounds__(LEAP_GEN_THREADS) void leap_general_kernel(const uint4* __restrict__ planes,
                                                                         const uint32_t* __restrict__ lens, long n, int w4,
                                                                         int x, int o, int ext, int gm, int gi, OutMap out) {
     constexpr int NL = 2 * K + 1, T = LEAP_GEN_THREADS, SLOT = NL * T;
-    extern __shared__ short s_ring[];
+    extern __shared__ uint32_t s_ring32[];
     const int t = threadIdx.x;
-    short* const r_en = s_ring + t;
-    short* const r_ip = r_en + gm * SLOT;
-    short* const r_dp = r_ip + gi * SLOT;
+    EnT* const r_en = reinterpret_cast<EnT*>(s_ring32) + t;
+    EnT* const r_ip = r_en + gm * SLOT;
+    EnT* const r_dp = r_ip + gi * SLOT;
     const long i = (long)blockIdx.x * T + t;
     if (i >= n) return;
     const uint32_t ln = lens[i];
@@ -892,32 +922,37 @@ __global__ __launch_bounds__(LEAP_GEN_THREADS) void leap_general_kernel(const ui
     int result = -1;
     // e = 0: only the main diagonal is live (LV_BAG.cpp:102-104,131-147)
 #pragma unroll
-    for (int j = 0; j < NL; j++) r_en[j * T] = -2, r_ip[j * T] = -2, r_dp[j * T] = -2;
+    for (int j = 0; j < NL; j++) { /* every slot starts as "never reached" (see the note on guards below) */
+        for (int q = 0; q < gm; q++) r_en[q * SLOT + j * T] = (EnT)0;
+        for (int q = 0; q < gi; q++) r_ip[q * SLOT + j * T] = (EnT)0, r_dp[q * SLOT + j * T] = (EnT)0;
+    }
     {
         int e0 = vw_next_one<W64>(mask[K], 0);
         e0 = e0 > len ? len : e0;
-        r_en[K * T] = (short)e0;
+        r_en[K * T] = (EnT)(e0 + 2);
         if (e0 == len) result = 0;
     }
     for (int e = 1; e <= ASM_LEAP_AF_THRESHOLD && result < 0; e++) {
-        const short* const en_o = r_en + ((e - o) & (gm - 1)) * SLOT;
-        const short* const en_x = r_en + ((e - x) & (gm - 1)) * SLOT;
-        const short* const ip_e = r_ip + ((e - ext) & (gi - 1)) * SLOT;
-        const short* const dp_e = r_dp + ((e - ext) & (gi - 1)) * SLOT;
-        short* const en_w = r_en + (e & (gm - 1)) * SLOT;
-        short* const ip_w = r_ip + (e & (gi - 1)) * SLOT;
-        short* const dp_w = r_dp + (e & (gi - 1)) * SLOT;
-        const bool has_o = e >= o, has_e = e >= ext, has_x = e >= x;
+        const EnT* const en_o = r_en + ((e - o) & (gm - 1)) * SLOT;
+        const EnT* const en_x = r_en + ((e - x) & (gm - 1)) * SLOT;
+        const EnT* const ip_e = r_ip + ((e - ext) & (gi - 1)) * SLOT;
+        const EnT* const dp_e = r_dp + ((e - ext) & (gi - 1)) * SLOT;
+        EnT* const en_w = r_en + (e & (gm - 1)) * SLOT;
+        EnT* const ip_w = r_ip + (e & (gi - 1)) * SLOT;
+        EnT* const dp_w = r_dp + (e & (gi - 1)) * SLOT;
+        // The reference guards these reads with e >= o, e >= x, e >= ext (LV_BAG.cpp:166-187).  Here the guards are implied:
+        // for e < o the slot of generation e - o is that of a generation not written yet (ring depth > o), still "never
+        // reached" from the initial fill; unguarded, the five reads issue back to back instead of a branch and a wait each.
         bool pass = false;
 #pragma unroll
         for (int j = 0; j < NL; j++) {
             const int d = j - K;
             const int top = d >= 0 ? 1 : 0, bot = d <= 0 ? 1 : 0;
-            const int e_up = (j > 0 && has_o) ? (int)en_o[(j > 0 ? j - 1 : 0) * T] : -2;
-            const int i_up = (j > 0 && has_e) ? (int)ip_e[(j > 0 ? j - 1 : 0) * T] : -2;
-            const int e_dn = (j < NL - 1 && has_o) ? (int)en_o[(j < NL - 1 ? j + 1 : j) * T] : -2;
-            const int d_dn = (j < NL - 1 && has_e) ? (int)dp_e[(j < NL - 1 ? j + 1 : j) * T] : -2;
-            const int own = has_x ? (int)en_x[j * T] : -2;
+            const int e_up = j > 0 ? (int)en_o[(j > 0 ? j - 1 : 0) * T] - 2 : -2;
+            const int i_up = j > 0 ? (int)ip_e[(j > 0 ? j - 1 : 0) * T] - 2 : -2;
+            const int e_dn = j < NL - 1 ? (int)en_o[(j < NL - 1 ? j + 1 : j) * T] - 2 : -2;
+            const int d_dn = j < NL - 1 ? (int)dp_e[(j < NL - 1 ? j + 1 : j) * T] - 2 : -2;
+            const int own = (int)en_x[j * T] - 2;
             int inew = -2, dnew = -2;
             if (e_up >= 0 && e_up > i_up)
                 inew = e_up + top; /* LV_BAG.cpp:166-167 */
@@ -942,7 +977,7 @@ __global__ __launch_bounds__(LEAP_GEN_THREADS) void leap_general_kernel(const ui
                     if (conv <= ASM_LEAP_AF_THRESHOLD) pass = true;
                 }
             }
-            en_w[j * T] = (short)enew, ip_w[j * T] = (short)inew, dp_w[j * T] = (short)dnew;
+            en_w[j * T] = (EnT)(enew + 2), ip_w[j * T] = (EnT)(inew + 2), dp_w[j * T] = (EnT)(dnew + 2);
         }
         if (pass) result = e; /* final_ED (LV_BAG.cpp:228,356-358) */
     }
@@ -961,21 +996,37 @@ __global__ __launch_bounds__(LEAP_GEN_THREADS) void leap_general_kernel(const ui
 // optimum; pairs that do not finish by then (or with |n-m| > K) are appended to `todo` for the full-matrix kernel.
 // --------------------------------------------------------------------------------------------------------
 #define NW_WFA_K 7
-template <int K, int W64>
+#define NW_WFA_K2 15 /* second pass over the pairs the first band could not settle (maxlen <= 128 only: 31 masks of 4 dwords) */
+struct WfaRings { /* ring depths of the banded wavefront: `M` needs scores s-o and s-x, I and D need s-ext; slot = score mod depth (scalar) */
+    int gm, gi;
+    __host__ WfaRings(int x, int o, int e) : gm((x > o ? x : o) + 1), gi(e + 1) {}
+    __host__ size_t lds_bytes(int nl, int threads, size_t elem) const { return ((size_t)(gm + 2 * gi) * nl * threads * elem + 3) & ~(size_t)3; }
+};
+// EnT: bytes when every position + 2 fits (values are stored + 2, 0 = never reached), else shorts.  LISTED: the pairs come from
+// `in_list[0 .. *in_count)` (the previous pass's todo list) instead of 0..n.
+template <int K, int W64, typename EnT, bool LISTED>
 __global__ __launch_bounds__(LEAP_GEN_THREADS) void nw_wfa_kernel(const uint4* __restrict__ planes,
                                                                   const uint32_t* __restrict__ lens, long n, int w4, int x,
                                                                   int o, int ext, int gm, int gi, OutMap out,
+                                                                  const uint32_t* __restrict__ in_list, const uint32_t* __restrict__ in_count,
                                                                   uint32_t* __restrict__ todo, uint32_t* __restrict__ todo_count) {
     constexpr int NL = 2 * K + 1, T = LEAP_GEN_THREADS, SLOT = NL * T;
-    extern __shared__ short s_ring[];
+    extern __shared__ uint32_t s_ring32[];
+    EnT* const s_ring = reinterpret_cast<EnT*>(s_ring32);
     const int t = threadIdx.x;
-    short* const r_m = s_ring + t;
-    short* const r_i = r_m + gm * SLOT;
-    short* const r_d = r_i + gi * SLOT;
-    const long i = (long)blockIdx.x * T + t;
+    EnT* const r_m = s_ring + t;
+    EnT* const r_i = r_m + gm * SLOT;
+    EnT* const r_d = r_i + gi * SLOT;
+    const long slot_id = (long)blockIdx.x * T + t;
+    long i = slot_id;
+    bool have = slot_id < n;
+    if constexpr (LISTED) {
+        have = slot_id < (long)*in_count;
+        i = have ? (long)in_list[slot_id] : 0;
+    }
     int result = 0;
     bool unresolved = false;
-    if (i < n) {
+    if (have) {
         const uint32_t ln = lens[i];
         const int m = (int)(ln & 0xffffu), nn = (int)(ln >> 16);
         const int df = nn - m, adf = df < 0 ? -df : df;
@@ -1012,35 +1063,43 @@ __global__ __launch_bounds__(LEAP_GEN_THREADS) void nw_wfa_kernel(const uint4* _
             // |d| <= (s - o) / ext + 1 (a bound that never shrinks), and their neighbours are read before they are ever written
             for (int q = 0; q < gm; q++)
 #pragma unroll
-                for (int j = 0; j < NL; j++) r_m[q * SLOT + j * T] = -2;
+                for (int j = 0; j < NL; j++) r_m[q * SLOT + j * T] = (EnT)0;
             for (int q = 0; q < gi; q++)
 #pragma unroll
-                for (int j = 0; j < NL; j++) r_i[q * SLOT + j * T] = -2, r_d[q * SLOT + j * T] = -2;
+                for (int j = 0; j < NL; j++) r_i[q * SLOT + j * T] = (EnT)0, r_d[q * SLOT + j * T] = (EnT)0;
             {
                 const int e0 = vw_next_one<W64>(mask[K], 0); /* <= min(m, n) */
-                r_m[K * T] = (short)e0;
+                r_m[K * T] = (EnT)(e0 + 2);
                 if (df == 0 && e0 >= m) result = 0;
             }
+            // ring slots by score: scalar counters instead of a modulo (s, s-o, s-x, s-ext advance together)
+            int sl_w = 0, sl_o = gm - o % gm, sl_x = gm - x % gm; /* slot of s, s-o, s-x in the M ring at s = 0 */
+            int sj_w = 0, sj_e = gi - ext % gi;                    /* slot of s, s-ext in the I/D rings */
+            sl_o = sl_o == gm ? 0 : sl_o, sl_x = sl_x == gm ? 0 : sl_x, sj_e = sj_e == gi ? 0 : sj_e;
             for (int s = 1; s <= bound && result < 0; s++) {
-                const short* const m_o = r_m + ((s - o) & (gm - 1)) * SLOT;
-                const short* const m_x = r_m + ((s - x) & (gm - 1)) * SLOT;
-                const short* const i_e = r_i + ((s - ext) & (gi - 1)) * SLOT;
-                const short* const d_e = r_d + ((s - ext) & (gi - 1)) * SLOT;
-                short* const m_w = r_m + (s & (gm - 1)) * SLOT;
-                short* const i_w = r_i + (s & (gi - 1)) * SLOT;
-                short* const d_w = r_d + (s & (gi - 1)) * SLOT;
-                const bool has_o = s >= o, has_e = s >= ext, has_x = s >= x;
+                sl_w = sl_w + 1 == gm ? 0 : sl_w + 1, sl_o = sl_o + 1 == gm ? 0 : sl_o + 1, sl_x = sl_x + 1 == gm ? 0 : sl_x + 1;
+                sj_w = sj_w + 1 == gi ? 0 : sj_w + 1, sj_e = sj_e + 1 == gi ? 0 : sj_e + 1;
+                const EnT* const m_o = r_m + sl_o * SLOT;
+                const EnT* const m_x = r_m + sl_x * SLOT;
+                const EnT* const i_e = r_i + sj_e * SLOT;
+                const EnT* const d_e = r_d + sj_e * SLOT;
+                EnT* const m_w = r_m + sl_w * SLOT;
+                EnT* const i_w = r_i + sj_w * SLOT;
+                EnT* const d_w = r_d + sj_w * SLOT;
+                // No "s >= o" style guards on the reads: for s < o the slot of s - o is the slot of a score that has not been
+                // written yet (ring depth > o), which still holds the initial "never reached"; likewise s - x and s - ext.
+                // Unguarded, the five reads of a lane issue back to back instead of one scalar branch and one wait each.
                 const int dmax = s < o ? 0 : (s - o) / ext + 1; /* wave-uniform: every thread is at the same score */
                 int done = 0;
 #pragma unroll
                 for (int j = 0; j < NL; j++) {
                     const int d = j - K;
                     if ((d < 0 ? -d : d) > dmax) continue;
-                    const int m_lo = (j > 0 && has_o) ? (int)m_o[(j > 0 ? j - 1 : 0) * T] : -2;
-                    const int i_lo = (j > 0 && has_e) ? (int)i_e[(j > 0 ? j - 1 : 0) * T] : -2;
-                    const int m_hi = (j < NL - 1 && has_o) ? (int)m_o[(j < NL - 1 ? j + 1 : j) * T] : -2;
-                    const int d_hi = (j < NL - 1 && has_e) ? (int)d_e[(j < NL - 1 ? j + 1 : j) * T] : -2;
-                    const int own = has_x ? (int)m_x[j * T] : -2;
+                    const int m_lo = j > 0 ? (int)m_o[(j > 0 ? j - 1 : 0) * T] - 2 : -2;
+                    const int i_lo = j > 0 ? (int)i_e[(j > 0 ? j - 1 : 0) * T] - 2 : -2;
+                    const int m_hi = j < NL - 1 ? (int)m_o[(j < NL - 1 ? j + 1 : j) * T] - 2 : -2;
+                    const int d_hi = j < NL - 1 ? (int)d_e[(j < NL - 1 ? j + 1 : j) * T] - 2 : -2;
+                    const int own = (int)m_x[j * T] - 2;
                     int inew = m_lo > i_lo ? m_lo : i_lo;      /* reference character consumed: i stays, j = i + d */
                     inew = (inew >= 0 && inew + d <= nn) ? inew : -2;
                     int dnew = m_hi > d_hi ? m_hi : d_hi;      /* read character consumed */
@@ -1051,7 +1110,7 @@ __global__ __launch_bounds__(LEAP_GEN_THREADS) void nw_wfa_kernel(const uint4* _
                     int mnew = -2;
                     if (st >= 0) mnew = vw_next_one<W64>(mask[j], st);
                     if (d == df && mnew >= m) done = 1;
-                    m_w[j * T] = (short)mnew, i_w[j * T] = (short)inew, d_w[j * T] = (short)dnew;
+                    m_w[j * T] = (EnT)(mnew + 2), i_w[j * T] = (EnT)(inew + 2), d_w[j * T] = (EnT)(dnew + 2);
                 }
                 if (done) result = s;
             }
@@ -1068,7 +1127,7 @@ __global__ __launch_bounds__(LEAP_GEN_THREADS) void nw_wfa_kernel(const uint4* _
         base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
         if (unresolved) todo[base + lane] = (uint32_t)i;
     }
-    if (i < n && !unresolved) out.put(i, result);
+    if (have && !unresolved) out.put(i, result);
 }
 
 // Persistent, lane-refilling form of leap_unit_kernel<K,W64>: a pair needs final_ED+1 generations (mean ~8, max >30

@@ -324,16 +324,16 @@ __global__ __launch_bounds__(LEAP_BANDG_THREADS) void leap_band_general_kernel(c
             EnT* const en_w = r_en + (e & (gm - 1)) * slot;
             EnT* const ip_w = r_ip + (e & (gi - 1)) * slot;
             EnT* const dp_w = r_dp + (e & (gi - 1)) * slot;
-            const bool has_o = e >= o, has_e = e >= ext, has_x = e >= x;
+            // no e >= o / e >= x / e >= ext guards: the slot of a generation before 0 is one not written yet, still zero
             bool pass = false;
             for (int l = k - dmax; l <= k + dmax; l++) {
                 const int d = l - k;
                 const int top = d >= 0 ? 1 : 0, bot = d <= 0 ? 1 : 0;
-                const int e_up = has_o ? (int)en_o[l * T] - 2 : -2;       /* lane l-1 sits at row l */
-                const int i_up = has_e ? (int)ip_e[l * T] - 2 : -2;
-                const int e_dn = has_o ? (int)en_o[(l + 2) * T] - 2 : -2; /* lane l+1 */
-                const int d_dn = has_e ? (int)dp_e[(l + 2) * T] - 2 : -2;
-                const int own = has_x ? (int)en_x[(l + 1) * T] - 2 : -2;
+                const int e_up = (int)en_o[l * T] - 2;       /* lane l-1 sits at row l */
+                const int i_up = (int)ip_e[l * T] - 2;
+                const int e_dn = (int)en_o[(l + 2) * T] - 2; /* lane l+1 */
+                const int d_dn = (int)dp_e[(l + 2) * T] - 2;
+                const int own = (int)en_x[(l + 1) * T] - 2;
                 int inew = -2, dnew = -2;
                 if (e_up >= 0 && e_up > i_up)
                     inew = e_up + top; /* LV_BAG.cpp:166-167 */
@@ -495,15 +495,16 @@ __global__ __launch_bounds__(LEAP_QUAD_THREADS) void leap_quad_kernel(const uint
                 EnT* const en_w = r_en + (e & (gm - 1)) * slot;
                 EnT* const ip_w = r_ip + (e & (gi - 1)) * slot;
                 EnT* const dp_w = r_dp + (e & (gi - 1)) * slot;
-                const bool has_o = e >= o, has_e = e >= ext, has_x = e >= x;
+                // The reference guards these reads with e >= o, e >= x, e >= ext (LV_BAG.cpp:166-187); here the slot of a generation
+                // before 0 is the slot of one not written yet (ring depth > penalty), still zero from the initial fill
                 for (int l = k - dmax + q; l <= k + dmax; l += 4) {
                     const int d = l - k;
                     const int top = d >= 0 ? 1 : 0, bot = d <= 0 ? 1 : 0;
-                    const int e_up = has_o ? (int)en_o[l * P] - 2 : -2;       /* lane l-1 sits at row l */
-                    const int i_up = has_e ? (int)ip_e[l * P] - 2 : -2;
-                    const int e_dn = has_o ? (int)en_o[(l + 2) * P] - 2 : -2; /* lane l+1 */
-                    const int d_dn = has_e ? (int)dp_e[(l + 2) * P] - 2 : -2;
-                    const int own = has_x ? (int)en_x[(l + 1) * P] - 2 : -2;
+                    const int e_up = (int)en_o[l * P] - 2;       /* lane l-1 sits at row l */
+                    const int i_up = (int)ip_e[l * P] - 2;
+                    const int e_dn = (int)en_o[(l + 2) * P] - 2; /* lane l+1 */
+                    const int d_dn = (int)dp_e[(l + 2) * P] - 2;
+                    const int own = (int)en_x[(l + 1) * P] - 2;
                     int inew = -2, dnew = -2;
                     if (e_up >= 0 && e_up > i_up)
                         inew = e_up + top; /* LV_BAG.cpp:166-167 */
