@@ -57,7 +57,7 @@ struct asm_handle {
     int leap_quad = 3;                    /* LEAP, wide band: four threads per pair (ASM_LEAP_QUAD bit 0: unit penalties, bit 1: general) */
     bool leap_band = true;                /* LEAP, wide band: thread per pair with the band in LDS (ASM_LEAP_BAND=0: wave per pair) */
     int ring_bytes = -1;                  /* thread-per-pair generation rings as bytes: -1 = where it pays, 0 / 1 force (ASM_RING_BYTES) */
-    bool nw_wfa_second = true;            /* affine NW: second wavefront pass with the wider band (ASM_NW_WFA2=0: straight to the full matrix) */
+    int nw_wfa_second = 1;                /* affine NW: second wavefront pass with the wider band — 1: eight threads per pair, 2: thread per pair, 0: straight to the full matrix (ASM_NW_WFA2) */
     bool nw_wfa = true;                   /* affine NW: banded wavefront first, full matrix for the rest (ASM_NW_WFA=0: full matrix only) */
     std::vector<hipEvent_t> prof_ev;      /* asm_profile_enable: 8 events per recorded asm_run_benchmark_async call */
     std::vector<unsigned> prof_mask;      /* which of a call's four kernels were launched */
@@ -306,8 +306,21 @@ static int launch_nw_wfa(asm_handle* h, const asm_bucket& b, const asm_params* p
     }
     if (!bytes) launch_nw_wfa_pass<NW_WFA_K, W64, uint16_t, false>(h, b, p, out, nullptr, nullptr, list_a + 1, list_a);
     const uint32_t* rest = list_a;
-    if constexpr (W64 == 2) {
-        if (h->nw_wfa_second && rg.lds_bytes(2 * NW_WFA_K2 + 1, LEAP_GEN_THREADS, 1) <= 64 * 1024) {
+    const size_t en = b.maxlen + 2 <= 255 ? 1 : 2;
+    if (h->nw_wfa_second == 1 && nw_oct_lds(2 * W64, NW_WFA_K2, rg.gm, rg.gi, en) <= 64 * 1024) {
+        /* the unsettled percent or two: eight threads per pair, |d| <= 15 (asm_wave.h) */
+        const dim3 grid((unsigned)std::min<int64_t>((b.n + NW_OCT_PAIRS - 1) / NW_OCT_PAIRS, (int64_t)h->num_cus * 16));
+        if (en == 1)
+            hipLaunchKernelGGL((nw_oct_kernel<2 * W64, uint8_t>), grid, dim3(NW_OCT_THREADS), nw_oct_lds(2 * W64, NW_WFA_K2, rg.gm, rg.gi, 1),
+                               h->stream, b.planes, b.lens, (long)b.n, b.w4, NW_WFA_K2, (int)p->x, (int)p->o, (int)p->e, rg.gm, rg.gi, out,
+                               (const uint32_t*)(list_a + 1), (const uint32_t*)list_a, list_b + 1, list_b);
+        else
+            hipLaunchKernelGGL((nw_oct_kernel<2 * W64, uint16_t>), grid, dim3(NW_OCT_THREADS), nw_oct_lds(2 * W64, NW_WFA_K2, rg.gm, rg.gi, 2),
+                               h->stream, b.planes, b.lens, (long)b.n, b.w4, NW_WFA_K2, (int)p->x, (int)p->o, (int)p->e, rg.gm, rg.gi, out,
+                               (const uint32_t*)(list_a + 1), (const uint32_t*)list_a, list_b + 1, list_b);
+        rest = list_b;
+    } else if constexpr (W64 == 2) {
+        if (h->nw_wfa_second == 2 && rg.lds_bytes(2 * NW_WFA_K2 + 1, LEAP_GEN_THREADS, 1) <= 64 * 1024) { /* A/B: thread per pair */
             launch_nw_wfa_pass<NW_WFA_K2, 2, uint8_t, true>(h, b, p, out, list_a + 1, list_a, list_b + 1, list_b);
             rest = list_b;
         }
@@ -504,7 +517,7 @@ int asm_create(asm_handle** out, int device) {
     if ((env = getenv("ASM_PERSIST_WIDE"))) h->persist_wide = env[0] != '0';
     if ((env = getenv("ASM_NW_BANDED"))) h->nw_banded = env[0] != '0';
     if ((env = getenv("ASM_NW_WFA"))) h->nw_wfa = env[0] != '0';
-    if ((env = getenv("ASM_NW_WFA2"))) h->nw_wfa_second = env[0] != '0';
+    if ((env = getenv("ASM_NW_WFA2"))) h->nw_wfa_second = atoi(env);
     if ((env = getenv("ASM_RING_BYTES"))) h->ring_bytes = atoi(env);
     if ((env = getenv("ASM_LEAP_BAND"))) h->leap_band = env[0] != '0';
     if ((env = getenv("ASM_LEAP_QUAD"))) h->leap_quad = atoi(env);

@@ -1076,16 +1076,26 @@ __global__ __launch_bounds__(LEAP_GEN_THREADS) void nw_wfa_kernel(const uint4* _
             int sl_w = 0, sl_o = gm - o % gm, sl_x = gm - x % gm; /* slot of s, s-o, s-x in the M ring at s = 0 */
             int sj_w = 0, sj_e = gi - ext % gi;                    /* slot of s, s-ext in the I/D rings */
             sl_o = sl_o == gm ? 0 : sl_o, sl_x = sl_x == gm ? 0 : sl_x, sj_e = sj_e == gi ? 0 : sj_e;
+            using LdsEl = __attribute__((address_space(3))) EnT;
+            const uint32_t a_m = (uint32_t)(uintptr_t)(LdsEl*)r_m, a_i = (uint32_t)(uintptr_t)(LdsEl*)r_i, a_d = (uint32_t)(uintptr_t)(LdsEl*)r_d;
+            const int m2 = m + 2;
             for (int s = 1; s <= bound && result < 0; s++) {
                 sl_w = sl_w + 1 == gm ? 0 : sl_w + 1, sl_o = sl_o + 1 == gm ? 0 : sl_o + 1, sl_x = sl_x + 1 == gm ? 0 : sl_x + 1;
                 sj_w = sj_w + 1 == gi ? 0 : sj_w + 1, sj_e = sj_e + 1 == gi ? 0 : sj_e + 1;
-                const EnT* const m_o = r_m + sl_o * SLOT;
-                const EnT* const m_x = r_m + sl_x * SLOT;
-                const EnT* const i_e = r_i + sj_e * SLOT;
-                const EnT* const d_e = r_d + sj_e * SLOT;
-                EnT* const m_w = r_m + sl_w * SLOT;
-                EnT* const i_w = r_i + sj_w * SLOT;
-                EnT* const d_w = r_d + sj_w * SLOT;
+                // The seven slot addresses of this score, each pinned in a VGPR: a DS instruction takes one VGPR and an
+                // immediate, and left alone the compiler re-adds the (scalar) slot offset in front of every access.
+                uint32_t p_mo = a_m + (uint32_t)(sl_o * SLOT * (int)sizeof(EnT)), p_mx = a_m + (uint32_t)(sl_x * SLOT * (int)sizeof(EnT));
+                uint32_t p_ie = a_i + (uint32_t)(sj_e * SLOT * (int)sizeof(EnT)), p_de = a_d + (uint32_t)(sj_e * SLOT * (int)sizeof(EnT));
+                uint32_t p_mw = a_m + (uint32_t)(sl_w * SLOT * (int)sizeof(EnT)), p_iw = a_i + (uint32_t)(sj_w * SLOT * (int)sizeof(EnT));
+                uint32_t p_dw = a_d + (uint32_t)(sj_w * SLOT * (int)sizeof(EnT));
+                asm volatile("" : "+v"(p_mo), "+v"(p_mx), "+v"(p_ie), "+v"(p_de), "+v"(p_mw), "+v"(p_iw), "+v"(p_dw));
+                const LdsEl* const m_o = (const LdsEl*)(uintptr_t)p_mo;
+                const LdsEl* const m_x = (const LdsEl*)(uintptr_t)p_mx;
+                const LdsEl* const i_e = (const LdsEl*)(uintptr_t)p_ie;
+                const LdsEl* const d_e = (const LdsEl*)(uintptr_t)p_de;
+                LdsEl* const m_w = (LdsEl*)(uintptr_t)p_mw;
+                LdsEl* const i_w = (LdsEl*)(uintptr_t)p_iw;
+                LdsEl* const d_w = (LdsEl*)(uintptr_t)p_dw;
                 // No "s >= o" style guards on the reads: for s < o the slot of s - o is the slot of a score that has not been
                 // written yet (ring depth > o), which still holds the initial "never reached"; likewise s - x and s - ext.
                 // Unguarded, the five reads of a lane issue back to back instead of one scalar branch and one wait each.
@@ -1095,22 +1105,23 @@ __global__ __launch_bounds__(LEAP_GEN_THREADS) void nw_wfa_kernel(const uint4* _
                 for (int j = 0; j < NL; j++) {
                     const int d = j - K;
                     if ((d < 0 ? -d : d) > dmax) continue;
-                    const int m_lo = j > 0 ? (int)m_o[(j > 0 ? j - 1 : 0) * T] - 2 : -2;
-                    const int i_lo = j > 0 ? (int)i_e[(j > 0 ? j - 1 : 0) * T] - 2 : -2;
-                    const int m_hi = j < NL - 1 ? (int)m_o[(j < NL - 1 ? j + 1 : j) * T] - 2 : -2;
-                    const int d_hi = j < NL - 1 ? (int)d_e[(j < NL - 1 ? j + 1 : j) * T] - 2 : -2;
-                    const int own = (int)m_x[j * T] - 2;
+                    // all values in the stored form u = position + 2 (0 = never reached, valid from 2)
+                    const int m_lo = j > 0 ? (int)m_o[(j > 0 ? j - 1 : 0) * T] : 0;
+                    const int i_lo = j > 0 ? (int)i_e[(j > 0 ? j - 1 : 0) * T] : 0;
+                    const int m_hi = j < NL - 1 ? (int)m_o[(j < NL - 1 ? j + 1 : j) * T] : 0;
+                    const int d_hi = j < NL - 1 ? (int)d_e[(j < NL - 1 ? j + 1 : j) * T] : 0;
+                    const int own = (int)m_x[j * T];
                     int inew = m_lo > i_lo ? m_lo : i_lo;      /* reference character consumed: i stays, j = i + d */
-                    inew = (inew >= 0 && inew + d <= nn) ? inew : -2;
-                    int dnew = m_hi > d_hi ? m_hi : d_hi;      /* read character consumed */
-                    dnew = (dnew >= 0 && dnew + 1 <= m) ? dnew + 1 : -2;
-                    int st = (own >= 0 && own + 1 <= m && own + 1 + d <= nn) ? own + 1 : -2;
+                    inew = (inew >= 2 && inew + (d - 2) <= nn) ? inew : 0;
+                    int dnew = m_hi > d_hi ? m_hi : d_hi;      /* read character consumed: i + 1 */
+                    dnew = (dnew >= 2 && dnew < m2) ? dnew + 1 : 0;
+                    int st = (own >= 2 && own < m2 && own + (d - 1) <= nn) ? own + 1 : 0;
                     st = inew > st ? inew : st;
                     st = dnew > st ? dnew : st;
-                    int mnew = -2;
-                    if (st >= 0) mnew = vw_next_one<W64>(mask[j], st);
-                    if (d == df && mnew >= m) done = 1;
-                    m_w[j * T] = (EnT)(mnew + 2), i_w[j * T] = (EnT)(inew + 2), d_w[j * T] = (EnT)(dnew + 2);
+                    int mnew = 0;
+                    if (st >= 2) mnew = vw_next_one<W64>(mask[j], st - 2) + 2;
+                    if (d == df && mnew >= m2) done = 1;
+                    m_w[j * T] = (EnT)mnew, i_w[j * T] = (EnT)inew, d_w[j * T] = (EnT)dnew;
                 }
                 if (done) result = s;
             }

@@ -560,6 +560,150 @@ static inline hipError_t launch_leap_quad(hipStream_t stream, const uint4* plane
 }
 
 // --------------------------------------------------------------------------------------------------------
+// Affine NW, banded wavefront, EIGHT THREADS PER PAIR — the second pass of launch_nw_wfa.  The pairs the thread-per-pair pass
+// (nw_wfa_kernel, |d| <= 7, mismatch vectors in registers) could not settle are a percent or two of a batch: too few to fill
+// the chip with one thread each (every thread would walk ~800 lane-steps alone on its SIMD), so here the lanes of a pair are
+// dealt round-robin to eight threads, as leap_quad_kernel does, with the rings [slot][lane row][pair] and the planes in LDS
+// and the band half-width K a run-time value.  Recurrence, exactness bound and todo list as nw_wfa_kernel.
+// --------------------------------------------------------------------------------------------------------
+#define NW_OCT_THREADS 64
+#define NW_OCT_Q 8
+#define NW_OCT_PAIRS (NW_OCT_THREADS / NW_OCT_Q)
+#define NW_OCT_PSTRIDE (NW_OCT_PAIRS + 1)
+
+// first i >= st on diagonal d (reference index i + d) at which the strings differ or either one ends (or i + d < 0)
+template <int PD, int TS>
+ASM_DEV int nw_diag_extend(const uint32_t* pl, int d, int st, int m, int nn) {
+    constexpr int PS = PD * TS;
+    const int lim = m < nn - d ? m : nn - d;
+    if (st >= lim || st + d < 0) return st;
+    int apos = st, bpos = st + d, p = st;
+    for (;;) {
+        const uint32_t diff = (leap_band_window<PD, TS>(pl, apos) ^ leap_band_window<PD, TS>(pl + 2 * PS, bpos)) |
+                              (leap_band_window<PD, TS>(pl + PS, apos) ^ leap_band_window<PD, TS>(pl + 3 * PS, bpos));
+        if (diff) {
+            p += __builtin_ctz(diff);
+            break;
+        }
+        p += 32, apos += 32, bpos += 32;
+        if (p >= lim) break;
+    }
+    return p < lim ? p : lim;
+}
+
+template <int W32, typename EnT>
+__global__ __launch_bounds__(NW_OCT_THREADS) void nw_oct_kernel(const uint4* __restrict__ planes, const uint32_t* __restrict__ lens,
+                                                                long n, int w4, int K, int x, int o, int ext, int gm, int gi,
+                                                                OutMap out, const uint32_t* __restrict__ in_list,
+                                                                const uint32_t* __restrict__ in_count, uint32_t* __restrict__ todo,
+                                                                uint32_t* __restrict__ todo_count) {
+    constexpr int P = NW_OCT_PAIRS, Q = NW_OCT_Q, TS = NW_OCT_PSTRIDE, PD = W32 + 1;
+    extern __shared__ uint32_t s_band[];
+    const int t = threadIdx.x, pr = t / Q, q = t % Q;
+    const int rows = 2 * K + 3; /* lane l at row l+1, guard rows 0 and 2K+2 stay "never reached" */
+    const int slot = rows * P;
+    uint32_t* const pl = s_band + pr;                                     /* [4][PD][TS] */
+    EnT* const r_m = reinterpret_cast<EnT*>(s_band + 4 * PD * TS) + pr;  /* [gm][rows][P] */
+    EnT* const r_i = r_m + gm * slot;                                     /* [gi][rows][P] */
+    EnT* const r_d = r_i + gi * slot;
+    const long count = (long)*in_count;
+    /* a fixed grid walks the list (its length is only known on the device) */
+    for (long first = (long)blockIdx.x * P; first < count; first += (long)gridDim.x * P) {
+    {
+        const int words = (int)(((size_t)(gm + 2 * gi) * slot * sizeof(EnT) + 3) / 4);
+        uint32_t* const base = s_band + 4 * PD * TS;
+        for (int w = t; w < words; w += NW_OCT_THREADS) base[w] = 0u;
+    }
+    const long slot_id = first + pr;
+    const bool have = slot_id < count;
+    const long i = have ? (long)in_list[slot_id] : 0;
+    int m = 0, nn = 0;
+    if (have) {
+        const uint32_t ln = lens[i];
+        m = (int)(ln & 0xffffu), nn = (int)(ln >> 16);
+        if (q < 4) { /* threads 0..3 of the group stage one plane each */
+#pragma unroll
+            for (int g = 0; g < (W32 + 3) / 4; g++) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (g < w4) v = planes[((long)q * w4 + g) * n + i];
+                uint32_t* dst = pl + (q * PD + 4 * g) * TS;
+                dst[0] = v.x;
+                if (4 * g + 1 < W32) dst[TS] = v.y;
+                if (4 * g + 2 < W32) dst[2 * TS] = v.z;
+                if (4 * g + 3 < W32) dst[3 * TS] = v.w;
+            }
+            pl[(q * PD + W32) * TS] = 0u;
+        }
+    }
+    const int df = nn - m, adf = df < 0 ? -df : df;
+    leap_quad_fence();
+    int result = have ? -1 : 0;
+    bool unresolved = have && adf > K;
+    if (unresolved) result = 0;
+    const int bound = 2 * o + (2 * K - adf) * ext;
+    if (result < 0) {
+        const int e0 = nw_diag_extend<PD, TS>(pl, 0, 0, m, nn);
+        if (q == 0) r_m[(K + 1) * P] = (EnT)(e0 + 2);
+        if (df == 0 && e0 >= m) result = 0;
+    }
+    leap_quad_fence();
+    int sl_w = 0, sl_o = gm - o % gm, sl_x = gm - x % gm, sj_w = 0, sj_e = gi - ext % gi;
+    sl_o = sl_o == gm ? 0 : sl_o, sl_x = sl_x == gm ? 0 : sl_x, sj_e = sj_e == gi ? 0 : sj_e;
+    for (int s = 1;; s++) {
+        if (result < 0 && s > bound) unresolved = true, result = 0;
+        if (__ballot(result < 0) == 0ull) break;
+        sl_w = sl_w + 1 == gm ? 0 : sl_w + 1, sl_o = sl_o + 1 == gm ? 0 : sl_o + 1, sl_x = sl_x + 1 == gm ? 0 : sl_x + 1;
+        sj_w = sj_w + 1 == gi ? 0 : sj_w + 1, sj_e = sj_e + 1 == gi ? 0 : sj_e + 1;
+        int done = 0;
+        if (result < 0) {
+            const EnT* const m_o = r_m + sl_o * slot;
+            const EnT* const m_x = r_m + sl_x * slot;
+            const EnT* const i_e = r_i + sj_e * slot;
+            const EnT* const d_e = r_d + sj_e * slot;
+            EnT* const m_w = r_m + sl_w * slot;
+            EnT* const i_w = r_i + sj_w * slot;
+            EnT* const d_w = r_d + sj_w * slot;
+            int dmax = s < o ? 0 : (s - o) / ext + 1;
+            dmax = dmax > K ? K : dmax;
+            for (int l = K - dmax + q; l <= K + dmax; l += Q) {
+                const int d = l - K;
+                const int m_lo = (int)m_o[l * P] - 2, i_lo = (int)i_e[l * P] - 2;             /* lane l-1 sits at row l */
+                const int m_hi = (int)m_o[(l + 2) * P] - 2, d_hi = (int)d_e[(l + 2) * P] - 2; /* lane l+1 */
+                const int own = (int)m_x[(l + 1) * P] - 2;
+                int inew = m_lo > i_lo ? m_lo : i_lo;      /* reference character consumed: i stays, j = i + d */
+                inew = (inew >= 0 && inew + d <= nn) ? inew : -2;
+                int dnew = m_hi > d_hi ? m_hi : d_hi;      /* read character consumed */
+                dnew = (dnew >= 0 && dnew + 1 <= m) ? dnew + 1 : -2;
+                int st = (own >= 0 && own + 1 <= m && own + 1 + d <= nn) ? own + 1 : -2;
+                st = inew > st ? inew : st;
+                st = dnew > st ? dnew : st;
+                int mnew = -2;
+                if (st >= 0) mnew = nw_diag_extend<PD, TS>(pl, d, st, m, nn);
+                if (d == df && mnew >= m) done = 1;
+                m_w[(l + 1) * P] = (EnT)(mnew + 2), i_w[(l + 1) * P] = (EnT)(inew + 2), d_w[(l + 1) * P] = (EnT)(dnew + 2);
+            }
+        }
+#pragma unroll
+        for (int off = 1; off < Q; off <<= 1) done |= __shfl_xor(done, off);
+        if (done && result < 0) result = s;
+        leap_quad_fence();
+    }
+    if (have && q == 0) {
+        if (unresolved)
+            todo[atomicAdd(todo_count, 1u)] = (uint32_t)i;
+        else
+            out.put(i, result);
+    }
+    leap_quad_fence(); /* the next round refills rings and planes */
+    }
+}
+
+static inline size_t nw_oct_lds(int w32, int K, int gm, int gi, size_t en_bytes) {
+    return (size_t)4 * (w32 + 1) * NW_OCT_PSTRIDE * sizeof(uint32_t) +
+           (((size_t)(gm + 2 * gi) * (2 * K + 3) * NW_OCT_PAIRS * en_bytes + 3) & ~(size_t)3);
+}
+
+// --------------------------------------------------------------------------------------------------------
 // Greedy, wave per pair.  Same step structure as greedy_kernel<K> (hurdle_matrix.h:285-434,568-597); lane t of the
 // wave is band lane t - k.
 // --------------------------------------------------------------------------------------------------------

@@ -54,6 +54,8 @@ print("ok")
     {"ASM_PERSIST_LEAP": "1", "ASM_LEAP_HINT": "0"},
     {"ASM_LEAP_HINT": "0"},
     {"ASM_NW_BANDED": "0", "ASM_NW_WFA": "0"},
+    {"ASM_NW_WFA2": "2", "ASM_RING_BYTES": "0"},
+    {"ASM_NW_WFA2": "0", "ASM_RING_BYTES": "1"},
     {"ASM_WAVE": "0"},
     {"ASM_LEAP_QUAD": "0"},
     {"ASM_LEAP_QUAD": "0", "ASM_LEAP_BAND": "0"},
