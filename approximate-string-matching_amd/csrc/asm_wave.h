@@ -148,9 +148,8 @@ ASM_DEV uint32_t leap_band_window(const uint32_t* plane, int pos) {
 }
 
 // first position p >= from at which lane d sees a mismatch (or either string has run out), as leap_lane_mask defines it
-template <int PD, int TS = LEAP_BAND_THREADS>
+template <int PD, int TS = LEAP_BAND_THREADS, int PS = PD * TS> /* PS: dwords between planes */
 ASM_DEV int leap_band_extend(const uint32_t* pl, int d, int from, int m, int nn) {
-    constexpr int PS = PD * TS; /* dwords between planes */
     const int s = d < 0 ? -d : d;
     int lim = d < 0 ? m + s : nn + s; /* d < 0: A[p-s] against B[p]; d >= 0: A[p] against B[p-s] */
     const int other = d < 0 ? nn : m;
@@ -400,7 +399,9 @@ static inline hipError_t launch_leap_band_general(hipStream_t stream, const uint
 // --------------------------------------------------------------------------------------------------------
 #define LEAP_QUAD_THREADS 64
 #define LEAP_QUAD_PAIRS 16
-#define LEAP_QUAD_PSTRIDE 17 /* plane column stride in dwords: odd, so the dwords one quad reads fall into different banks */
+/* planes in LDS pair-major: the 4 x PD dwords of a pair are contiguous (a window is two adjacent dwords: one address add, no
+ * multiply) and pairs are an odd number of dwords apart, so the sixteen quads start in different banks */
+#define LEAP_QUAD_PAIR_DWORDS(PD) (4 * (PD) + 1)
 
 ASM_DEV void leap_quad_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -417,18 +418,18 @@ template <int W32, typename EnT, bool UNIT>
 __global__ __launch_bounds__(LEAP_QUAD_THREADS) void leap_quad_kernel(const uint4* __restrict__ planes,
                                                                       const uint32_t* __restrict__ lens, long n, int w4, int k,
                                                                       int x, int o, int ext, int gm, int gi, OutMap out) {
-    constexpr int P = LEAP_QUAD_PAIRS, TS = LEAP_QUAD_PSTRIDE, PD = W32 + 1;
+    constexpr int P = LEAP_QUAD_PAIRS, PD = W32 + 1, PW = LEAP_QUAD_PAIR_DWORDS(PD);
     extern __shared__ uint32_t s_band[];
     const int t = threadIdx.x, pr = t >> 2, q = t & 3;
     const int rows = 2 * k + 3; /* lane l at row l+1, guard rows 0 and 2k+2 */
     const int slot = rows * P;  /* elements per ring slot */
-    uint32_t* const pl = s_band + pr;                                          /* [4][PD][TS] */
-    EnT* const r_en = reinterpret_cast<EnT*>(s_band + 4 * PD * TS) + pr;      /* [gm][rows][P] */
+    uint32_t* const pl = s_band + pr * PW;                                     /* [P][4][PD] (+1) */
+    EnT* const r_en = reinterpret_cast<EnT*>(s_band + P * PW) + pr;           /* [gm][rows][P] */
     EnT* const r_ip = r_en + gm * slot;                                        /* [gi][rows][P] (general penalties only) */
     EnT* const r_dp = r_ip + gi * slot;
     {
         const int words = (int)(((size_t)(gm + 2 * gi) * slot * sizeof(EnT) + 3) / 4);
-        uint32_t* const base = s_band + 4 * PD * TS;
+        uint32_t* const base = s_band + P * PW;
         for (int w = t; w < words; w += LEAP_QUAD_THREADS) base[w] = 0u;
     }
     const long i = (long)blockIdx.x * P + pr;
@@ -441,19 +442,19 @@ __global__ __launch_bounds__(LEAP_QUAD_THREADS) void leap_quad_kernel(const uint
         for (int g = 0; g < (W32 + 3) / 4; g++) {
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (g < w4) v = planes[((long)q * w4 + g) * n + i];
-            uint32_t* dst = pl + (q * PD + 4 * g) * TS;
+            uint32_t* dst = pl + q * PD + 4 * g;
             dst[0] = v.x;
-            if (4 * g + 1 < W32) dst[TS] = v.y;
-            if (4 * g + 2 < W32) dst[2 * TS] = v.z;
-            if (4 * g + 3 < W32) dst[3 * TS] = v.w;
+            if (4 * g + 1 < W32) dst[1] = v.y;
+            if (4 * g + 2 < W32) dst[2] = v.z;
+            if (4 * g + 3 < W32) dst[3] = v.w;
         }
-        pl[(q * PD + W32) * TS] = 0u;
+        pl[q * PD + W32] = 0u;
     }
     const int len = m > nn ? m : nn; /* benchmark_utils.h:162 */
     leap_quad_fence();
     int result = live ? -1 : 0;
     if (live) { /* e = 0: main diagonal only (LV_BAG.cpp:102-104,131-147); the four threads compute the same value */
-        int e0 = leap_band_extend<PD, TS>(pl, 0, 0, m, nn);
+        int e0 = leap_band_extend<PD, 1, PD>(pl, 0, 0, m, nn);
         e0 = e0 > len ? len : e0;
         if (q == 0) r_en[(k + 1) * P] = (EnT)(e0 + 2);
         if (e0 == len) result = 0;
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(LEAP_QUAD_THREADS) void leap_quad_kernel(const uint
                     int enew = -2;
                     if (st >= 0) {
                         const int from = st > len ? len : st;
-                        int r = leap_band_extend<PD, TS>(pl, d, from, m, nn); /* count_ID_length, :9-23 */
+                        int r = leap_band_extend<PD, 1, PD>(pl, d, from, m, nn); /* count_ID_length, :9-23 */
                         r = r > len ? len : r;
                         enew = st > len ? st : r;
                         const int diff = d < 0 ? -d : d;
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(LEAP_QUAD_THREADS) void leap_quad_kernel(const uint
                     int enew = -2;
                     if (st >= 0) {
                         const int from = st > len ? len : st;
-                        int r = leap_band_extend<PD, TS>(pl, d, from, m, nn); /* count_ID_length, :9-23 */
+                        int r = leap_band_extend<PD, 1, PD>(pl, d, from, m, nn); /* count_ID_length, :9-23 */
                         r = r > len ? len : r;
                         enew = st > len ? st : r;
                         if (enew == len) { /* :220-238 */
@@ -541,7 +542,7 @@ __global__ __launch_bounds__(LEAP_QUAD_THREADS) void leap_quad_kernel(const uint
 }
 
 static inline size_t leap_quad_lds(int w32, int k, int gm, int gi, size_t en_bytes) {
-    return (size_t)4 * (w32 + 1) * LEAP_QUAD_PSTRIDE * sizeof(uint32_t) +
+    return (size_t)LEAP_QUAD_PAIRS * LEAP_QUAD_PAIR_DWORDS(w32 + 1) * sizeof(uint32_t) +
            (((size_t)(gm + 2 * gi) * (2 * k + 3) * LEAP_QUAD_PAIRS * en_bytes + 3) & ~(size_t)3);
 }
 
@@ -569,12 +570,10 @@ static inline hipError_t launch_leap_quad(hipStream_t stream, const uint4* plane
 #define NW_OCT_THREADS 64
 #define NW_OCT_Q 8
 #define NW_OCT_PAIRS (NW_OCT_THREADS / NW_OCT_Q)
-#define NW_OCT_PSTRIDE (NW_OCT_PAIRS + 1)
 
 // first i >= st on diagonal d (reference index i + d) at which the strings differ or either one ends (or i + d < 0)
-template <int PD, int TS>
+template <int PD, int TS, int PS>
 ASM_DEV int nw_diag_extend(const uint32_t* pl, int d, int st, int m, int nn) {
-    constexpr int PS = PD * TS;
     const int lim = m < nn - d ? m : nn - d;
     if (st >= lim || st + d < 0) return st;
     int apos = st, bpos = st + d, p = st;
@@ -597,13 +596,13 @@ __global__ __launch_bounds__(NW_OCT_THREADS) void nw_oct_kernel(const uint4* __r
                                                                 OutMap out, const uint32_t* __restrict__ in_list,
                                                                 const uint32_t* __restrict__ in_count, uint32_t* __restrict__ todo,
                                                                 uint32_t* __restrict__ todo_count) {
-    constexpr int P = NW_OCT_PAIRS, Q = NW_OCT_Q, TS = NW_OCT_PSTRIDE, PD = W32 + 1;
+    constexpr int P = NW_OCT_PAIRS, Q = NW_OCT_Q, PD = W32 + 1, PW = LEAP_QUAD_PAIR_DWORDS(PD);
     extern __shared__ uint32_t s_band[];
     const int t = threadIdx.x, pr = t / Q, q = t % Q;
     const int rows = 2 * K + 3; /* lane l at row l+1, guard rows 0 and 2K+2 stay "never reached" */
     const int slot = rows * P;
-    uint32_t* const pl = s_band + pr;                                     /* [4][PD][TS] */
-    EnT* const r_m = reinterpret_cast<EnT*>(s_band + 4 * PD * TS) + pr;  /* [gm][rows][P] */
+    uint32_t* const pl = s_band + pr * PW;                                /* [P][4][PD] (+1), as leap_quad_kernel */
+    EnT* const r_m = reinterpret_cast<EnT*>(s_band + P * PW) + pr;       /* [gm][rows][P] */
     EnT* const r_i = r_m + gm * slot;                                     /* [gi][rows][P] */
     EnT* const r_d = r_i + gi * slot;
     const long count = (long)*in_count;
@@ -611,7 +610,7 @@ __global__ __launch_bounds__(NW_OCT_THREADS) void nw_oct_kernel(const uint4* __r
     for (long first = (long)blockIdx.x * P; first < count; first += (long)gridDim.x * P) {
     {
         const int words = (int)(((size_t)(gm + 2 * gi) * slot * sizeof(EnT) + 3) / 4);
-        uint32_t* const base = s_band + 4 * PD * TS;
+        uint32_t* const base = s_band + P * PW;
         for (int w = t; w < words; w += NW_OCT_THREADS) base[w] = 0u;
     }
     const long slot_id = first + pr;
@@ -626,13 +625,13 @@ __global__ __launch_bounds__(NW_OCT_THREADS) void nw_oct_kernel(const uint4* __r
             for (int g = 0; g < (W32 + 3) / 4; g++) {
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
                 if (g < w4) v = planes[((long)q * w4 + g) * n + i];
-                uint32_t* dst = pl + (q * PD + 4 * g) * TS;
+                uint32_t* dst = pl + q * PD + 4 * g;
                 dst[0] = v.x;
-                if (4 * g + 1 < W32) dst[TS] = v.y;
-                if (4 * g + 2 < W32) dst[2 * TS] = v.z;
-                if (4 * g + 3 < W32) dst[3 * TS] = v.w;
+                if (4 * g + 1 < W32) dst[1] = v.y;
+                if (4 * g + 2 < W32) dst[2] = v.z;
+                if (4 * g + 3 < W32) dst[3] = v.w;
             }
-            pl[(q * PD + W32) * TS] = 0u;
+            pl[q * PD + W32] = 0u;
         }
     }
     const int df = nn - m, adf = df < 0 ? -df : df;
@@ -642,7 +641,7 @@ __global__ __launch_bounds__(NW_OCT_THREADS) void nw_oct_kernel(const uint4* __r
     if (unresolved) result = 0;
     const int bound = 2 * o + (2 * K - adf) * ext;
     if (result < 0) {
-        const int e0 = nw_diag_extend<PD, TS>(pl, 0, 0, m, nn);
+        const int e0 = nw_diag_extend<PD, 1, PD>(pl, 0, 0, m, nn);
         if (q == 0) r_m[(K + 1) * P] = (EnT)(e0 + 2);
         if (df == 0 && e0 >= m) result = 0;
     }
@@ -678,7 +677,7 @@ __global__ __launch_bounds__(NW_OCT_THREADS) void nw_oct_kernel(const uint4* __r
                 st = inew > st ? inew : st;
                 st = dnew > st ? dnew : st;
                 int mnew = -2;
-                if (st >= 0) mnew = nw_diag_extend<PD, TS>(pl, d, st, m, nn);
+                if (st >= 0) mnew = nw_diag_extend<PD, 1, PD>(pl, d, st, m, nn);
                 if (d == df && mnew >= m) done = 1;
                 m_w[(l + 1) * P] = (EnT)(mnew + 2), i_w[(l + 1) * P] = (EnT)(inew + 2), d_w[(l + 1) * P] = (EnT)(dnew + 2);
             }
@@ -699,7 +698,7 @@ __global__ __launch_bounds__(NW_OCT_THREADS) void nw_oct_kernel(const uint4* __r
 }
 
 static inline size_t nw_oct_lds(int w32, int K, int gm, int gi, size_t en_bytes) {
-    return (size_t)4 * (w32 + 1) * NW_OCT_PSTRIDE * sizeof(uint32_t) +
+    return (size_t)NW_OCT_PAIRS * LEAP_QUAD_PAIR_DWORDS(w32 + 1) * sizeof(uint32_t) +
            (((size_t)(gm + 2 * gi) * (2 * K + 3) * NW_OCT_PAIRS * en_bytes + 3) & ~(size_t)3);
 }
 
