@@ -45,7 +45,6 @@ struct asm_handle {
     int num_cus = 256;
     bool persist = true;                  /* Greedy: lane-refilling persistent kernel (ASM_PERSIST=0 disables) */
     bool persist_leap = false;            /* LEAP: the plain one-pair-per-thread kernel is faster at 1e6 pairs (ASM_PERSIST_LEAP=1) */
-    int queue_dyn_permille = 0, queue_chunk = 128; /* persistent Greedy: share of the pairs handed out dynamically and pairs per draw (ASM_QUEUE_DYN, ASM_QUEUE_CHUNK); off — at C2 a wave's slice is 326 pairs and the draws of 3072 waves queue up on the counter: 0.153 -> 0.174 ms in the timed region at 500/128 */
     int refill_greedy = 8, refill_leap = 16; /* lanes that must be idle before a wave refills (tunable by env) */
     bool leap_hint = true;                /* LEAP scheduled by a work hint when one is given (ASM_LEAP_HINT=0 disables) */
     bool bucketing = true;                /* group mixed-length batches by width class (ASM_BUCKET=0 disables) */
@@ -221,18 +220,12 @@ static hipError_t launch_greedy(asm_handle* h, const asm_bucket& b, const Greedy
 #ifdef GREEDY_DIAG
     if (cig.ops == nullptr && g_diag_buf) cig.nops = (uint8_t*)g_diag_buf;
 #endif
-    QueueArgs qa{nullptr, 0, 0};
-    if (h->persist && h->queue_dyn_permille > 0 && h->queue_chunk > 0) {
-        qa = QueueArgs{h->d_pair_queue, h->queue_dyn_permille, h->queue_chunk};
-        const hipError_t e = hipMemsetAsync(h->d_pair_queue, 0, sizeof(unsigned long long), h->stream);
-        if (e != hipSuccess) return e;
-    }
     if (h->persist && ga.x == 1 && ga.o == 1 && ga.e == 1 && !ga.semi)
         return launch_persistent(h, greedy_persist_kernel<K, true>, b.n, (const uint4*)b.planes, (const uint32_t*)b.lens,
-                                 (long)b.n, b.w4, ga, out, cig, h->refill_greedy, qa);
+                                 (long)b.n, b.w4, ga, out, cig, h->refill_greedy);
     if (h->persist)
         return launch_persistent(h, greedy_persist_kernel<K, false>, b.n, (const uint4*)b.planes, (const uint32_t*)b.lens,
-                                 (long)b.n, b.w4, ga, out, cig, h->refill_greedy, qa);
+                                 (long)b.n, b.w4, ga, out, cig, h->refill_greedy);
     if constexpr (K <= 5) { /* the one-pair-per-thread A/B form (ASM_PERSIST=0) exists for the narrow bands only */
         hipLaunchKernelGGL(greedy_kernel<K>, dim3(grid_for(b.n)), dim3(ASM_BLOCK), 0, h->stream, b.planes, b.lens, (long)b.n,
                            b.w4, ga, out, cig);
@@ -522,8 +515,6 @@ int asm_create(asm_handle** out, int device) {
     if ((env = getenv("ASM_LEAP_BAND"))) h->leap_band = env[0] != '0';
     if ((env = getenv("ASM_LEAP_QUAD"))) h->leap_quad = atoi(env);
     if ((env = getenv("ASM_REFILL_GREEDY"))) h->refill_greedy = atoi(env);
-    if ((env = getenv("ASM_QUEUE_DYN"))) h->queue_dyn_permille = atoi(env) < 0 ? 0 : (atoi(env) > 1000 ? 1000 : atoi(env));
-    if ((env = getenv("ASM_QUEUE_CHUNK"))) h->queue_chunk = atoi(env) < 1 ? 1 : atoi(env);
     if ((env = getenv("ASM_REFILL_LEAP"))) h->refill_leap = atoi(env);
     *out = h;
     return ASM_OK;

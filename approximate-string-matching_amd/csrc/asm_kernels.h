@@ -419,51 +419,26 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_kernel(const uint4* __restri
 // (static split over the resident waves: ~n/3000 pairs each, so slices are balanced to a few percent) and its lanes pull
 // the next pair with wave-level bit tricks only — no memory atomics (a single global queue head saturates at ~88
 // dequeues/us on this chip, far below the refill rate of these kernels).
-// The static split leaves two things on the table: slices differ in total work (a few percent of standard deviation, and
-// the kernel lasts as long as its slowest wave), and when the kernel runs beside another one only part of its grid is
-// resident at first.  So the split covers the first (1000 - dyn_permille)/1000 of the pairs only, and a wave whose slice
-// is used up draws chunks of `chunk` pairs of the rest from a counter in device memory (zeroed by the launcher) — a few
-// thousand atomics per launch, well below that rate.
-struct QueueArgs {
-    unsigned long long* counter; /* nullptr: static split of everything */
-    int dyn_permille, chunk;
-};
+// Measured dead end (C2, 10^6 pairs, 3072 waves, ~120 us): drawing chunks of pairs from counters in device memory instead —
+// one counter, or eight per-XCD-group counters 128 B or 8 KB apart, with a static first chunk and stealing between groups —
+// costs ~7 ns of kernel time per draw whatever the layout (chunks of 16 / 64 / 256 pairs: 0.56 / 0.19 / 0.13 ms against 0.12):
+// the kernel hands out 8 pairs per nanosecond, and a wave stalls for two memory-side round trips per draw.  The wave-per-pair
+// kernels, where a chunk of 16 pairs lasts a wave ~100 us, do use such a queue (PairQueue, asm_wave.h).
 struct WaveQueue {
-    long next, end, pool_lo, pool_hi;
-    unsigned long long* counter;
-    int chunk;
-    bool dry;
-    ASM_DEV void init(long n, QueueArgs qa = QueueArgs{nullptr, 0, 0}) {
+    long next, end;
+    ASM_DEV void init(long n) {
         const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
         const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
-        const long n_dyn = (qa.counter && qa.chunk > 0) ? n * qa.dyn_permille / 1000 : 0;
-        const long n_static = n - n_dyn;
-        next = n_static * wave / nwaves;
-        end = n_static * (wave + 1) / nwaves;
-        pool_lo = n_static, pool_hi = n;
-        counter = qa.counter, chunk = qa.chunk;
-        dry = n_dyn == 0;
+        next = n * wave / nwaves;
+        end = n * (wave + 1) / nwaves;
     }
-    // lanes with need=true receive consecutive indices; returns -1 when everything is used up and -2 for "nothing this
-    // time, ask again" (the slice ran out in the middle of a refill and the pool has not been asked yet)
+    // lanes with need=true receive consecutive indices; returns -1 when the slice is used up
     ASM_DEV long pull(bool need) {
         const unsigned long long mask = __ballot(need);
         const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
         const long cnt = (long)__popcll(mask);
-        if (next >= end && !dry) { /* wave-uniform */
-            unsigned long long b = 0;
-            if ((threadIdx.x & 63) == 0) b = atomicAdd(counter, (unsigned long long)chunk);
-            const long base = pool_lo + (long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b) +
-                              ((long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32)) << 32);
-            if (base >= pool_hi) {
-                dry = true;
-            } else {
-                next = base;
-                end = base + chunk < pool_hi ? base + chunk : pool_hi;
-            }
-        }
         const long avail = end - next;
-        const long idx = need ? (rank < avail ? next + rank : (dry ? -1 : -2)) : -1;
+        const long idx = (need && rank < avail) ? next + rank : -1;
         next += cnt < avail ? cnt : avail;
         return idx;
     }
@@ -480,7 +455,7 @@ template <int K, bool UNIT> /* UNIT: x = o = e = 1 known at compile time (the be
 __global__ __launch_bounds__(ASM_BLOCK) void greedy_persist_kernel(const uint4* __restrict__ planes,
                                                                    const uint32_t* __restrict__ lens, long n, int w4,
                                                                    GreedyArgs args, OutMap out,
-                                                                   CigarSink cig, int refill_min, QueueArgs qa) {
+                                                                   CigarSink cig, int refill_min) {
     constexpr int NL = 2 * K + 1;
 #ifndef ASM_PERSIST_KEEP_LF
 #define ASM_PERSIST_KEEP_LF 5 /* largest K whose flipped lane vectors stay in registers; above it they are rebuilt per look-up */
@@ -496,7 +471,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_persist_kernel(const uint4* 
     long idx = -1, pair = 0;
     bool active = false, finished = true, exhausted = false;
     WaveQueue wq;
-    wq.init(n, qa);
+    wq.init(n);
 #pragma unroll
     for (int j = 0; j < NL; j++) {
         lo_[j] = v_make(0, 0);
@@ -532,7 +507,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_persist_kernel(const uint4* 
             if (need) {
                 idx = got;
                 active = got >= 0;
-                exhausted = got == -1; /* -2: the lane stays idle and asks again at the next refill */
+                exhausted = !active;
             }
             if (need && active) {
                 const V128 A0 = v_from_uint4(planes[((long)0 * w4) * n + idx]);
