@@ -108,7 +108,9 @@ __global__ __launch_bounds__(ASM_BLOCK) void leap_wave_kernel(const uint4* __res
 // finished.  Each wave therefore draws chunks of PAIR_QUEUE_CHUNK consecutive pairs from a counter in device memory (zeroed
 // by the launcher on the same stream): one atomic per chunk, far below the rate a single address sustains.
 // --------------------------------------------------------------------------------------------------------
+#ifndef PAIR_QUEUE_CHUNK
 #define PAIR_QUEUE_CHUNK 16
+#endif
 struct PairQueue {
     long chunk_end;
     ASM_DEV long grab(unsigned long long* queue) {
@@ -396,6 +398,11 @@ static inline hipError_t launch_leap_band_general(hipStream_t stream, const uint
 // order, so the only synchronisation between generations is a wave-scope fence that keeps the compiler from moving a read
 // of another thread's value above the writes of the generation before.
 // Same recurrences and results as leap_band_kernel / leap_band_general_kernel (LV::run, LV_BAG.cpp:127-245).
+// Measured and dropped: a persistent form with decoupled quads (every quad at its own generation, one lane per thread per
+// trip of the wave's loop, a quad whose pair has passed takes the next pair from a device-memory queue) — it removes the wait
+// for the slowest of the sixteen pairs (work grows with final_ED^2: ~1.6x the mean at C3), was bit-identical, and ran 1.31 ms
+// against 0.91 per 10^6 C3 pairs (0.52 against 0.19 at C2): every refill stalls the whole wave for two dependent global
+// round trips (lengths, then planes), 122 times per wave at 10^6 pairs.  It would need the next pair prefetched into registers.
 // --------------------------------------------------------------------------------------------------------
 #define LEAP_QUAD_THREADS 64
 #define LEAP_QUAD_PAIRS 16
