@@ -62,6 +62,9 @@ struct asm_handle {
     std::vector<unsigned> prof_mask;      /* which of a call's four kernels were launched */
     int prof_cap = 0;
     unsigned prof_select = 0xfu;          /* which kernels are bracketed: bit 0 pack, 1 NW, 2 LEAP, 3 Greedy */
+    void* d_sort = nullptr;               /* wide-band LEAP: keys, permutation and radix-sort scratch of the global work sort */
+    size_t sort_cap = 0;
+    bool leap_sort = true;                /* ASM_LEAP_SORT=0: work-sort inside workgroups only */
     uint32_t* d_todo = nullptr;           /* affine NW: [0] = count, [1..] = bucket slots the wavefront band could not settle */
     size_t todo_cap = 0;
     /* Device memory of batches is recycled instead of freed: a streamed file, or the reference-shaped per-pair objects, create
@@ -514,6 +517,7 @@ int asm_create(asm_handle** out, int device) {
     if ((env = getenv("ASM_RING_BYTES"))) h->ring_bytes = atoi(env);
     if ((env = getenv("ASM_LEAP_BAND"))) h->leap_band = env[0] != '0';
     if ((env = getenv("ASM_LEAP_QUAD"))) h->leap_quad = atoi(env);
+    if ((env = getenv("ASM_LEAP_SORT"))) h->leap_sort = env[0] != '0';
     if ((env = getenv("ASM_REFILL_GREEDY"))) h->refill_greedy = atoi(env);
     if ((env = getenv("ASM_REFILL_LEAP"))) h->refill_leap = atoi(env);
     *out = h;
@@ -526,6 +530,7 @@ int asm_destroy(asm_handle* h) {
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     if (h->d_pair_queue) (void)hipFree(h->d_pair_queue);
+    if (h->d_sort) (void)hipFree(h->d_sort);
     if (h->pack_stream) (void)hipStreamDestroy(h->pack_stream);
     if (h->ev_packed) (void)hipEventDestroy(h->ev_packed);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -1214,11 +1219,38 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
             /* wide band: four threads per pair, generation rings and planes in LDS (asm_wave.h) */
             const RingGeometry rg(p->x, p->o, p->e);
             const int w32 = (b.maxlen + 31) / 32;
+            const int32_t* const qhint = h->leap_hint ? hint : nullptr;
+            /* long-running cases (long strings or general penalties): sort the whole bucket by the hint — one 6-bit radix pass —
+             * and let every single-wave workgroup take sixteen neighbours of the order; short ones sort inside the workgroup */
+            const uint32_t* qperm = nullptr;
+            if (qhint && h->leap_sort && (b.maxlen > 128 || !unit)) {
+                const size_t n = (size_t)b.n;
+                size_t tmp_bytes = 0;
+                HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (uint8_t*)nullptr, (uint8_t*)nullptr, (uint32_t*)nullptr,
+                                                             (uint32_t*)nullptr, (int)n, 0, 6, h->stream));
+                const size_t need = 2 * n + 8 * n + tmp_bytes + 256; /* keys, keys', idx, perm, temp */
+                if (h->sort_cap < need) {
+                    if (h->d_sort) (void)hipFree(h->d_sort);
+                    h->d_sort = nullptr, h->sort_cap = 0;
+                    HIPCHK(h, hipMalloc((void**)&h->d_sort, need));
+                    h->sort_cap = need;
+                }
+                uint32_t* const d_idx = (uint32_t*)h->d_sort;
+                uint32_t* const d_perm = d_idx + n;
+                uint8_t* const d_keys = (uint8_t*)(d_perm + n);
+                uint8_t* const d_keys2 = d_keys + n;
+                void* const d_tmp = (void*)(((uintptr_t)(d_keys2 + n) + 255) & ~(uintptr_t)255);
+                const int div = unit ? 1 : (int)(p->e < p->x ? p->e : p->x);
+                hipLaunchKernelGGL(leap_sort_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, qhint, out, (long)n,
+                                   div, d_keys, d_idx);
+                HIPCHK(h, hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_keys, d_keys2, d_idx, d_perm, (int)n, 0, 6, h->stream));
+                qperm = d_perm;
+            }
 #define LEAP_QUAD(W)                                                                                                          \
     HIPCHK(h, (b.maxlen + 2 <= 255 ? launch_leap_quad<W, uint8_t>(h->stream, planes, lens, b.n, b.w4, (int)p->k, unit, (int)p->x, \
-                                                                  (int)p->o, (int)p->e, rg.gm, rg.gi, out)                      \
+                                                                  (int)p->o, (int)p->e, rg.gm, rg.gi, out, qhint, qperm)        \
                                    : launch_leap_quad<W, uint16_t>(h->stream, planes, lens, b.n, b.w4, (int)p->k, unit, (int)p->x, \
-                                                                   (int)p->o, (int)p->e, rg.gm, rg.gi, out)))
+                                                                   (int)p->o, (int)p->e, rg.gm, rg.gi, out, qhint, qperm)))
             if (w32 <= 4) LEAP_QUAD(4);
             else if (w32 <= 5) LEAP_QUAD(5);
             else if (w32 <= 6) LEAP_QUAD(6);
@@ -1632,7 +1664,16 @@ int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, in
     }
     // Greedy depends only on the packed planes, NW -> LEAP form their own chain (LEAP is scheduled by the NW penalties):
     // run Greedy on a side stream so that the two chains fill each other's launch gaps and tail waves.
-    const bool fork = h->overlap && d_greedy && (d_nw || d_leap) && !rc;
+    // Without NW in the mask, wide-band LEAP (four threads per pair, asm_wave.h) is scheduled by the Greedy penalties instead:
+    // Greedy first, on the same stream — at wide bands both kernels are VALU-bound and side by side they gain nothing (C3:
+    // 23.8 ms against 23.6 in a row), while the work-sorted LEAP saves a quarter of its time.
+    const bool greedy_first = d_greedy && d_leap && !d_nw && p->k > 5 && h->leap_quad != 0 && h->leap_hint && h->wave_kernels && !rc;
+    if (greedy_first) {
+        PROF(3, 0, main_stream)
+        rc = asm_align_batch_async(h, b, ASM_GREEDY, p, d_greedy);
+        PROF(3, 1, main_stream)
+    }
+    const bool fork = h->overlap && d_greedy && (d_nw || d_leap) && !rc && !greedy_first;
     if (fork) {
         HIPCHK(h, hipEventRecord(h->ev_fork, main_stream));
         HIPCHK(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
@@ -1651,12 +1692,12 @@ int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, in
     /* LEAP is scheduled by the NW penalties just computed (same work, sorted inside each workgroup) */
     if (!rc && d_leap) {
         PROF(2, 0, main_stream)
-        rc = asm_align_batch_hinted_async(h, b, ASM_LEAP, p, d_nw, d_leap);
+        rc = asm_align_batch_hinted_async(h, b, ASM_LEAP, p, greedy_first ? d_greedy : d_nw, d_leap);
         PROF(2, 1, main_stream)
     }
     if (fork) {
         if (!rc) HIPCHK(h, hipStreamWaitEvent(main_stream, h->ev_join, 0));
-    } else if (!rc && d_greedy) {
+    } else if (!rc && d_greedy && !greedy_first) {
         PROF(3, 0, main_stream)
         rc = asm_align_batch_async(h, b, ASM_GREEDY, p, d_greedy);
         PROF(3, 1, main_stream)

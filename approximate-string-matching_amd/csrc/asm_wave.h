@@ -421,26 +421,68 @@ ASM_DEV int quad_or(int v) {
     return v;
 }
 
-template <int W32, typename EnT, bool UNIT>
-__global__ __launch_bounds__(LEAP_QUAD_THREADS) void leap_quad_kernel(const uint4* __restrict__ planes,
+// WAVES > 1 is the work-sorted form (as leap_unit_hint_kernel): with a per-pair work estimate at hand — the NW penalties, or
+// the Greedy penalties where `_run_benchmark` has no NW —, the workgroup counting-sorts its 16 x WAVES pairs by it and each of
+// its waves takes one slice of the order, so that the sixteen pairs a wave waits for need about the same number of generations
+// (the work of a pair grows with final_ED^2).  A workgroup keeps its LDS and wave slots until its slowest wave is done, so
+// sorting more pairs per workgroup does not pay (16 waves: 0.83 ms against 0.78 with 4 per 10^6 C3 pairs); for the long-running
+// cases the launcher sorts the whole bucket instead (one 6-bit radix pass) and hands single-wave workgroups a permutation.  The hint only changes the schedule, never a result.  Each wave has its own LDS block.
+template <int W32, typename EnT, bool UNIT, int WAVES>
+__global__ __launch_bounds__(LEAP_QUAD_THREADS * WAVES) void leap_quad_kernel(const uint4* __restrict__ planes,
                                                                       const uint32_t* __restrict__ lens, long n, int w4, int k,
-                                                                      int x, int o, int ext, int gm, int gi, OutMap out) {
+                                                                      int x, int o, int ext, int gm, int gi, OutMap out,
+                                                                      const int32_t* __restrict__ hint,
+                                                                      const uint32_t* __restrict__ perm) {
     constexpr int P = LEAP_QUAD_PAIRS, PD = W32 + 1, PW = LEAP_QUAD_PAIR_DWORDS(PD);
-    extern __shared__ uint32_t s_band[];
-    const int t = threadIdx.x, pr = t >> 2, q = t & 3;
+    extern __shared__ uint32_t s_band_all[];
+    const int t = threadIdx.x & 63, pr = t >> 2, q = t & 3, wv = threadIdx.x >> 6;
     const int rows = 2 * k + 3; /* lane l at row l+1, guard rows 0 and 2k+2 */
     const int slot = rows * P;  /* elements per ring slot */
+    const int ring_words = (int)(((size_t)(gm + 2 * gi) * slot * sizeof(EnT) + 3) / 4);
+    uint32_t* const s_band = s_band_all + wv * (P * PW + ring_words);          /* this wave's block */
     uint32_t* const pl = s_band + pr * PW;                                     /* [P][4][PD] (+1) */
     EnT* const r_en = reinterpret_cast<EnT*>(s_band + P * PW) + pr;           /* [gm][rows][P] */
     EnT* const r_ip = r_en + gm * slot;                                        /* [gi][rows][P] (general penalties only) */
     EnT* const r_dp = r_ip + gi * slot;
     {
-        const int words = (int)(((size_t)(gm + 2 * gi) * slot * sizeof(EnT) + 3) / 4);
         uint32_t* const base = s_band + P * PW;
-        for (int w = t; w < words; w += LEAP_QUAD_THREADS) base[w] = 0u;
+        for (int w = t; w < ring_words; w += LEAP_QUAD_THREADS) base[w] = 0u;
     }
-    const long i = (long)blockIdx.x * P + pr;
-    const bool live = i < n;
+    long i = ((long)blockIdx.x * WAVES + wv) * P + pr;
+    bool live = i < n;
+    if (WAVES == 1 && perm != nullptr && live) i = (long)perm[i]; /* globally work-sorted: slot -> pair (leap_sort_keys_kernel + radix sort) */
+    if constexpr (WAVES > 1) {
+        constexpr int BP = P * WAVES; /* pairs per workgroup */
+        __shared__ uint16_t s_sorted[BP];
+        __shared__ int s_bin[64];
+        const int tt = threadIdx.x;
+        const long base = (long)blockIdx.x * BP;
+        const int cnt = (n - base) < BP ? (int)(n - base) : BP;
+        if (tt < 64) s_bin[tt] = 0;
+        __syncthreads();
+        int key = -1;
+        if (tt < cnt) {
+            int hv = hint[out.index(base + tt)];
+            if (!UNIT) hv /= (ext < x ? ext : x); /* penalties, not edits: bring them into the 64 bins */
+            key = hv < 0 ? 63 : (hv > 63 ? 63 : hv);
+            atomicAdd(&s_bin[key], 1);
+        }
+        __syncthreads();
+        if (tt == 0) { /* exclusive scan of 64 bins */
+            int run = 0;
+            for (int b = 0; b < 64; b++) {
+                const int c = s_bin[b];
+                s_bin[b] = run;
+                run += c;
+            }
+        }
+        __syncthreads();
+        if (key >= 0) s_sorted[atomicAdd(&s_bin[key], 1)] = (uint16_t)tt;
+        __syncthreads();
+        const int rank = wv * P + pr;
+        live = rank < cnt;
+        i = live ? base + s_sorted[rank] : 0;
+    }
     int m = 0, nn = 0;
     if (live) { /* thread q of the quad stages plane q: read plane 0/1, reference plane 0/1 */
         const uint32_t ln = lens[i];
@@ -553,16 +595,38 @@ static inline size_t leap_quad_lds(int w32, int k, int gm, int gi, size_t en_byt
            (((size_t)(gm + 2 * gi) * (2 * k + 3) * LEAP_QUAD_PAIRS * en_bytes + 3) & ~(size_t)3);
 }
 
+// keys of the global work sort: the hint (penalties) scaled into 64 bins, and the identity permutation to carry along
+__global__ __launch_bounds__(256) void leap_sort_keys_kernel(const int32_t* __restrict__ hint, OutMap out, long n, int div,
+                                                             uint8_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int hv = hint[out.index(j)] / div;
+    keys[j] = (uint8_t)(hv < 0 ? 63 : (hv > 63 ? 63 : hv));
+    idx[j] = (uint32_t)j;
+}
+
 template <int W32, typename EnT>
 static inline hipError_t launch_leap_quad(hipStream_t stream, const uint4* planes, const uint32_t* lens, int64_t n, int w4, int k,
-                                          bool unit, int x, int o, int e, int gm, int gi, OutMap out) {
+                                          bool unit, int x, int o, int e, int gm, int gi, OutMap out, const int32_t* hint,
+                                          const uint32_t* perm) {
+    const size_t lds1 = unit ? leap_quad_lds(W32, k, 2, 0, sizeof(EnT)) : leap_quad_lds(W32, k, gm, gi, sizeof(EnT));
+    if (hint && !perm && 4 * lds1 + 512 <= 64 * 1024) { /* work-sorted inside workgroups of four waves (64 pairs) */
+        const dim3 grid((unsigned)((n + 4 * LEAP_QUAD_PAIRS - 1) / (4 * LEAP_QUAD_PAIRS))), block(4 * LEAP_QUAD_THREADS);
+        if (unit)
+            hipLaunchKernelGGL((leap_quad_kernel<W32, EnT, true, 4>), grid, block, 4 * lds1, stream, planes, lens, (long)n, w4, k, 1, 1, 1,
+                               2, 0, out, hint, nullptr);
+        else
+            hipLaunchKernelGGL((leap_quad_kernel<W32, EnT, false, 4>), grid, block, 4 * lds1, stream, planes, lens, (long)n, w4, k, x, o,
+                               e, gm, gi, out, hint, nullptr);
+        return hipGetLastError();
+    }
     const dim3 grid((unsigned)((n + LEAP_QUAD_PAIRS - 1) / LEAP_QUAD_PAIRS)), block(LEAP_QUAD_THREADS);
     if (unit) {
-        hipLaunchKernelGGL((leap_quad_kernel<W32, EnT, true>), grid, block, leap_quad_lds(W32, k, 2, 0, sizeof(EnT)), stream, planes,
-                           lens, (long)n, w4, k, 1, 1, 1, 2, 0, out);
+        hipLaunchKernelGGL((leap_quad_kernel<W32, EnT, true, 1>), grid, block, lds1, stream, planes, lens, (long)n, w4, k, 1, 1, 1, 2, 0,
+                           out, nullptr, perm);
     } else {
-        hipLaunchKernelGGL((leap_quad_kernel<W32, EnT, false>), grid, block, leap_quad_lds(W32, k, gm, gi, sizeof(EnT)), stream,
-                           planes, lens, (long)n, w4, k, x, o, e, gm, gi, out);
+        hipLaunchKernelGGL((leap_quad_kernel<W32, EnT, false, 1>), grid, block, lds1, stream, planes, lens, (long)n, w4, k, x, o, e, gm,
+                           gi, out, nullptr, perm);
     }
     return hipGetLastError();
 }

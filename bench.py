@@ -275,7 +275,8 @@ def run(args, asm, eng, torch, dist, stream, rank, world, cfg, params, first, n,
             return
         seq = [("pack", lambda: eng.pack_async(b))]
         for a in aligners:
-            hint = d_nw if a == asm.LEAP else None  # as asm_run_benchmark_async does: LEAP scheduled by the NW penalties
+            # as asm_run_benchmark_async does: LEAP scheduled by the NW penalties, or by the Greedy penalties where NW is not run
+            hint = (d_nw if d_nw is not None else d_greedy) if a == asm.LEAP else None
             seq.append((asm.ALIGNER_NAMES[a], lambda a=a, hint=hint: eng.align_hinted_async(b, a, params, hint, d_pen[a])))
         for name, fn in seq:
             t = eng.timer()

@@ -395,6 +395,34 @@ def test_leap_work_hint_changes_schedule_not_results(asm, engine, oracle):
         engine.free(d_nw), engine.free(d_leap)
 
 
+@pytest.mark.parametrize("wl,n,k,pen", [("C3", 6000, 30, (1, 1, 1)), ("C2", 9000, 8, (1, 1, 1)), ("C2", 9000, 12, (2, 3, 1)),
+                                         ("C5", 9000, 9, (1, 1, 1)), ("C5", 6000, 20, (4, 6, 2))])
+def test_wide_band_leap_work_sorted(asm, engine, oracle, wl, n, k, pen):
+    """Wide-band LEAP (four threads per pair) scheduled by a work estimate: sorted inside workgroups (short strings, unit
+    penalties) or over the whole bucket (one radix pass: long strings, general penalties, each class of a mixed-length batch);
+    hinted by NW, by junk, and — asm_run_benchmark_async without NW, the C3 case — by the Greedy penalties of the same call."""
+    cfg, _, _ = asm.workload(wl)
+    hb = asm.generate_pairs(cfg, 5, n)
+    x, o, e = pen
+    params = asm.Params.default(k=k, x=x, o=o, e=e)
+    batch = engine.upload(hb, asm.GREEDY_CLEAN)
+    want = oracle.leap(hb, k, x, o, e)
+    d_hint, d_leap, d_greedy = engine.malloc(4 * n), engine.malloc(4 * n), engine.malloc(4 * n)
+    engine.align_async(batch, asm.NW, params, d_hint)
+    engine.align_hinted_async(batch, asm.LEAP, params, d_hint, d_leap)
+    _check("hinted by NW", engine.to_host(d_leap, n), want, hb)
+    junk = (np.arange(n, dtype=np.int32) * 7919) % 300 - 50
+    engine._chk(engine.lib.asm_memcpy_h2d(engine.h, d_hint, junk.ctypes.data, 4 * n))
+    engine.align_hinted_async(batch, asm.LEAP, params, d_hint, d_leap)
+    _check("hinted by junk", engine.to_host(d_leap, n), want, hb)
+    engine.memset_async(d_leap, 0xff, 4 * n)
+    engine.run_benchmark_async(batch, params, None, d_leap, d_greedy, None, repack=True)  # no NW: Greedy first, LEAP sorted by it
+    _check("run_benchmark leap", engine.to_host(d_leap, n), want, hb)
+    _check("run_benchmark greedy", engine.to_host(d_greedy, n), oracle.greedy(hb, k, x, o, e, mode=1), hb)
+    for d in (d_hint, d_leap, d_greedy):
+        engine.free(d)
+
+
 def test_seed_hit_batches_mapper_shape(asm, engine, oracle):
     """The reference mapper's call shape (GASMA/mapper/main.cpp:67-96): resident reference text, one Greedy alignment per
     seed hit against reference[start, start + len + 1), start = pos ? pos - 1 : 0; MAPQ = 60 + cost."""

@@ -58,6 +58,7 @@ print("ok")
     {"ASM_NW_WFA2": "0", "ASM_RING_BYTES": "1"},
     {"ASM_WAVE": "0"},
     {"ASM_LEAP_QUAD": "0"},
+    {"ASM_LEAP_SORT": "0"},
     {"ASM_LEAP_QUAD": "0", "ASM_LEAP_BAND": "0"},
     {"ASM_BUCKET": "0"},
     {"ASM_REFILL_GREEDY": "1", "ASM_REFILL_LEAP": "64", "ASM_PERSIST_LEAP": "1", "ASM_LEAP_HINT": "0"},

@@ -12,6 +12,7 @@ eng = m.Engine(0)
 n = 1_000_000
 tm = eng.timer()
 d = eng.malloc(4 * n)
+d_hint = eng.malloc(4 * n)
 for name, ks in (("C2", (6, 8, 16, 30, 45)), ("C3", (8, 30, 50))):
     cfg, _, _ = m.workload(name)
     batch = eng.generate(cfg, 0, n)
@@ -20,10 +21,14 @@ for name, ks in (("C2", (6, 8, 16, 30, 45)), ("C3", (8, 30, 50))):
             if name == "C3" and pen != (1, 1, 1) and k != 30:
                 continue
             p = m.Params.default(k=k, x=pen[0], o=pen[1], e=pen[2])
+            hint = None
+            if os.environ.get("AB_HINT"):  # schedule by the NW penalties of the same parameters, as asm_run_benchmark_async does
+                eng.align_async(batch, m.NW, p, d_hint)
+                hint = d_hint
             for it in range(2):
-                tm.start(); eng.align_async(batch, m.LEAP, p, d); tm.stop(); ms = tm.elapsed_ms()
+                tm.start(); eng.align_hinted_async(batch, m.LEAP, p, hint, d); tm.stop(); ms = tm.elapsed_ms()
             out = eng.to_host(d, n)
-            print("quad=%s %s pen %s k=%2d leap %8.3f ms  digest %s  mean %.3f" % (os.environ.get("ASM_LEAP_QUAD", "default"), name, pen, k, ms,
+            print("hint=%s quad=%s %s pen %s k=%2d leap %8.3f ms  digest %s  mean %.3f" % (os.environ.get("AB_HINT", "0"), os.environ.get("ASM_LEAP_QUAD", "default"), name, pen, k, ms,
                   hashlib.sha256(out.tobytes()).hexdigest()[:12], out.mean()), flush=True)
     del batch
 eng.close()
