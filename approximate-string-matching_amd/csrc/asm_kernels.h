@@ -451,8 +451,13 @@ struct WaveQueue {
 // wave-local queue (WaveQueue above), so every pass of the step body works on 64 live pairs.  The grid is sized to
 // what is resident (CUs x occupancy), not to n.
 // --------------------------------------------------------------------------------------------------------
+// K = 8, 9 (and 10 with unit penalties) fit 256 registers without scratch when asked to; left alone the allocator spreads into
+// the AGPR half and the kernel runs at one wave per SIMD instead of two.
+#ifndef GREEDY_PERSIST_MIN_WAVES
+#define GREEDY_PERSIST_MIN_WAVES(K, UNIT) (((K) == 8 || (K) == 9 || ((K) == 10 && (UNIT))) ? 2 : 1)
+#endif
 template <int K, bool UNIT> /* UNIT: x = o = e = 1 known at compile time (the benchmark's penalties): the multiplies fold away */
-__global__ __launch_bounds__(ASM_BLOCK) void greedy_persist_kernel(const uint4* __restrict__ planes,
+__global__ __launch_bounds__(ASM_BLOCK, GREEDY_PERSIST_MIN_WAVES(K, UNIT)) void greedy_persist_kernel(const uint4* __restrict__ planes,
                                                                    const uint32_t* __restrict__ lens, long n, int w4,
                                                                    GreedyArgs args, OutMap out,
                                                                    CigarSink cig, int refill_min) {
