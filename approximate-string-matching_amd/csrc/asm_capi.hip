@@ -1525,6 +1525,47 @@ int asm_simd_ed_batch_async(asm_handle* h, const asm_batch* b, int ed_threshold,
     return rc;
 }
 
+int asm_simd_ed_affine_batch_async(asm_handle* h, const asm_batch* b, int gap_threshold, int af_threshold, int x, int o, int e,
+                                   int32_t* d_ed) {
+    if (!h || !b || !d_ed) return fail(h, ASM_EINVAL, "asm_simd_ed_affine_batch_async: NULL argument");
+    if (gap_threshold < 1 || gap_threshold > ASM_FILTER_MAX_T)
+        return fail(h, ASM_EINVAL, "asm_simd_ed_affine_batch_async: gap threshold must be in [1, 32]");
+    if (af_threshold < 1 || af_threshold > 512)
+        return fail(h, ASM_EINVAL, "asm_simd_ed_affine_batch_async: affine threshold must be in [1, 512]");
+    if (x < 1 || x > 15 || o < 1 || o > 15 || e < 1 || e > o)
+        return fail(h, ASM_EINVAL, "asm_simd_ed_affine_batch_async: penalties must satisfy 1 <= e <= o <= 15, 1 <= x <= 15");
+    if (b->n == 0) return ASM_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    const RingGeometry rg(x, o, e);
+    const int rows = 2 * gap_threshold + 3;
+    int threads = 64;
+    while (threads > 16 && (size_t)(rg.gm + 2 * rg.gi) * rows * threads * sizeof(uint16_t) > 150 * 1024) threads >>= 1;
+    const size_t lds = (((size_t)(rg.gm + 2 * rg.gi) * rows * threads * sizeof(uint16_t)) + 3) & ~(size_t)3;
+    if (lds > 150 * 1024) return fail(h, ASM_EINVAL, "asm_simd_ed_affine_batch_async: generation rings exceed the LDS");
+    for (int q = 0; q < b->nb; q++) {
+        const asm_bucket& k = b->bk[q];
+        OutMap out;
+        out.out = d_ed;
+        out.order = k.order;
+        const dim3 grid((unsigned)((k.n + threads - 1) / threads)), block((unsigned)threads);
+        if (k.maxlen <= 128) {
+            if (lds > 64 * 1024)
+                HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&simd_ed_affine_kernel<2>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(simd_ed_affine_kernel<2>, grid, block, lds, h->stream, k.planes, k.lens, (long)k.n, k.w4, gap_threshold,
+                               af_threshold, x, o, e, rg.gm, rg.gi, out);
+        } else {
+            if (lds > 64 * 1024)
+                HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&simd_ed_affine_kernel<4>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(simd_ed_affine_kernel<4>, grid, block, lds, h->stream, k.planes, k.lens, (long)k.n, k.w4, gap_threshold,
+                               af_threshold, x, o, e, rg.gm, rg.gi, out);
+        }
+        HIPCHK(h, hipGetLastError());
+    }
+    return ASM_OK;
+}
+
 int asm_shd_filter_batch_async(asm_handle* h, const asm_batch* b, int max_error, int32_t* d_pass) {
     if (!h || !b || !d_pass) return fail(h, ASM_EINVAL, "asm_shd_filter_batch_async: NULL argument");
     if (max_error < 0 || max_error > ASM_SHD_MAX_ERROR)

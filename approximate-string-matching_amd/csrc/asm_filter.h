@@ -205,6 +205,100 @@ __global__ __launch_bounds__(SIMD_ED_THREADS) void simd_ed_kernel(const uint4* _
     events.put(i, ev);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// SIMD_ED in affine mode (init_affine / run_affine, SIMD_ED.cpp:435-616), CLEAN: every pair starts from the tables
+// init_affine leaves.  (The reference as run keeps the I/D/end tables of the pair before — run_affine writes them only where
+// its conditions hold and reset_affine touches none — so a pair's verdict depends on everything the object has seen; that
+// chain runs through every table cell and has no parallel form.  Clean = the reference's verdict for the first pair after
+// init_affine, which is how oracle/ref_harness_simd.cpp drives the compiled reference for the pin.)
+// One thread per pair; the recurrence is LV::run's (leap_general_kernel) over SIMD_ED's own lane masks (simd_lane_mask, rebuilt
+// per use) with the read's length as the target; generation rings of 2^a > max(x, o) and 2^b > ext generations in thread-
+// private LDS columns [slot][lane row][thread], stored + 2 so that the initial zero fill is "never reached" (which also stands
+// in for the e >= penalty guards, see leap_general_kernel).  Result: get_ED() = converge_ED, the smallest e + gap(lane
+// distance) <= af_threshold over the lanes that reach the end in the first generation in which one does; 1000000 —
+// reset_affine's value — for a pair that reaches the end at e = 0 (run_affine returns before converge_ED is written); -1 when
+// the pair does not pass.  blockDim.x threads (64, 32 or 16: whatever lets the rings fit the LDS).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int W64>
+__global__ __launch_bounds__(64) void simd_ed_affine_kernel(const uint4* __restrict__ planes, const uint32_t* __restrict__ lens,
+                                                            long n, int w4, int T, int af_t, int x, int o, int ext, int gm, int gi,
+                                                            OutMap out) {
+    extern __shared__ uint16_t s_afring[]; /* `end` [gm][rows][TH], I [gi][rows][TH], D [gi][rows][TH] */
+    const int TH = (int)blockDim.x, t = threadIdx.x;
+    const int rows = 2 * T + 3, mid = T + 1; /* lanes 1 .. 2T+1, guard rows 0 and 2T+2 (SIMD_ED.cpp:452-453) */
+    const int slot = rows * TH;
+    uint16_t* const r_en = s_afring + t;
+    uint16_t* const r_ip = r_en + gm * slot;
+    uint16_t* const r_dp = r_ip + gi * slot;
+    {
+        const int words = ((gm + 2 * gi) * slot + 1) / 2;
+        uint32_t* const base = reinterpret_cast<uint32_t*>(s_afring);
+        for (int w = t; w < words; w += TH) base[w] = 0u;
+    }
+    __syncthreads();
+    const long i = (long)blockIdx.x * TH + t;
+    if (i >= n) return;
+    const int m = (int)(lens[i] & 0xffffu);
+    const int len = m > 64 * W64 ? 64 * W64 : m;
+    VW<W64> A0, A1, B0, B1;
+    load_planes<W64>(planes, n, w4, i, A0, A1, B0, B1);
+    {
+        const VW<W64> lm = vw_low_ones<W64>(len);
+#pragma unroll
+        for (int q = 0; q < W64; q++) A0.w[q] &= lm.w[q], A1.w[q] &= lm.w[q], B0.w[q] &= lm.w[q], B1.w[q] &= lm.w[q];
+    }
+    int result = -2; /* -2: still running */
+    {   /* e = 0: only the main lane has a start (ED_GLOBAL, :474-477,497-516) */
+        const int e0 = simd_extend<W64>(simd_lane_mask<W64>(A0, A1, B0, B1, 0), 0, len);
+        r_en[mid * TH] = (uint16_t)(e0 + 2);
+        if (e0 == len) result = 1000000;
+    }
+    for (int e = 1; e <= af_t; e++) {
+        if (__ballot(result == -2) == 0ull) break;
+        if (result != -2) continue;
+        int dmax = e < o ? 0 : (e - o) / ext + 1; /* lanes a gap of this cost can have reached */
+        dmax = dmax > T ? T : dmax;
+        const uint16_t* const en_o = r_en + ((e - o) & (gm - 1)) * slot;
+        const uint16_t* const en_x = r_en + ((e - x) & (gm - 1)) * slot;
+        const uint16_t* const ip_e = r_ip + ((e - ext) & (gi - 1)) * slot;
+        const uint16_t* const dp_e = r_dp + ((e - ext) & (gi - 1)) * slot;
+        uint16_t* const en_w = r_en + (e & (gm - 1)) * slot;
+        uint16_t* const ip_w = r_ip + (e & (gi - 1)) * slot;
+        uint16_t* const dp_w = r_dp + (e & (gi - 1)) * slot;
+        int conv = 1000000;
+        for (int l = mid - dmax; l <= mid + dmax; l++) {
+            const int top = l >= mid ? 1 : 0, bot = l <= mid ? 1 : 0;
+            const int e_up = (int)en_o[(l - 1) * TH] - 2, i_up = (int)ip_e[(l - 1) * TH] - 2;
+            const int e_dn = (int)en_o[(l + 1) * TH] - 2, d_dn = (int)dp_e[(l + 1) * TH] - 2;
+            const int own = (int)en_x[l * TH] - 2;
+            int inew = -2, dnew = -2;
+            if (e_up >= 0 && e_up > i_up)
+                inew = e_up + top; /* :533-538 */
+            else if (i_up >= 0)
+                inew = i_up + top; /* :539-544 */
+            if (e_dn >= 0 && e_dn > d_dn)
+                dnew = e_dn + bot; /* :546-547 */
+            else if (d_dn >= 0)
+                dnew = d_dn + bot; /* :548-549 */
+            int st = own >= 0 ? own + 1 : -2; /* :551-558 */
+            st = inew > st ? inew : st;
+            st = dnew > st ? dnew : st;
+            int enew = -2;
+            if (st >= 0) {
+                enew = simd_extend<W64>(simd_lane_mask<W64>(A0, A1, B0, B1, l - mid), st, len); /* :579-581 */
+                if (enew == len) { /* :589-603 */
+                    const int diff = l < mid ? mid - l : l - mid;
+                    const int tc = e + (diff ? o + (diff - 1) * ext : 0);
+                    if (tc <= af_t && tc < conv) conv = tc;
+                }
+            }
+            en_w[l * TH] = (uint16_t)(enew + 2), ip_w[l * TH] = (uint16_t)(inew + 2), dp_w[l * TH] = (uint16_t)(dnew + 2);
+        }
+        if (conv != 1000000) result = conv; /* ED_pass: the generation loop ends (:609-610) */
+    }
+    out.put(i, result == -2 ? -1 : result);
+}
+
 // clean mode: every pair judged alone — never reached: fail; exact: 0; reached: final_ED + lane distance if <= T
 __global__ __launch_bounds__(ASM_BLOCK) void simd_ed_clean_kernel(int32_t* __restrict__ ev_to_ed, long n, int T) {
     const long i = (long)blockIdx.x * ASM_BLOCK + threadIdx.x;

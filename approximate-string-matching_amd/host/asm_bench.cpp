@@ -169,6 +169,13 @@ int main(int argc, char** argv) {
             sed.reset();
             sed.run();
             printf("simd_ed pass %d ED %d\n", sed.check_pass() ? 1 : 0, sed.get_ED());
+            SIMD_ED saf;  // the affine mode of the same class (SIMD_ED.h:50), every pair from clean tables
+            saf.init_affine(k, 200, ED_GLOBAL, x, o, e);
+            saf.load_reads((char*)pair_read.c_str(), (char*)pair_ref.c_str(), (int)pair_read.size());
+            saf.calculate_masks();
+            saf.reset();
+            saf.run();
+            printf("simd_ed affine pass %d ED %d\n", saf.check_pass() ? 1 : 0, saf.get_ED());
             return 0;
         }
         if (file.empty()) {

@@ -232,6 +232,15 @@ int asm_stream_seq_file(asm_handle* h, const char* path, const asm_params* p, in
 #define ASM_FILTER_CLEAN 1
 int asm_simd_ed_batch_async(asm_handle* h, const asm_batch* b, int ed_threshold, int shd_enable, int mode,
                             int32_t* state, int32_t* d_ed);
+/* SIMD_ED in affine mode (LEAP_SIMD/SIMD_ED.h:50, SIMD_ED.cpp:435-616): init_affine(gap_threshold, af_threshold, ED_GLOBAL, x,
+ * o, e) then, per pair, load_reads(read, ref, min(m, 256)) / calculate_masks() / reset() / run() / check_pass() / get_ED(), in
+ * CLEAN form: every pair starts from the tables init_affine leaves.  (The reference object keeps its I/D/end tables from pair to
+ * pair and never clears them, so as run a verdict depends on all pairs seen before; this entry point gives the verdict of the
+ * first pair after init_affine.)  d_ed[i] = get_ED() = converge_ED when the pair passes — 1000000 for a pair whose main lane
+ * reaches the end at e = 0, as the reference returns it —, -1 when it does not.  gap_threshold in [1, 32], af_threshold in
+ * [1, 512], 1 <= e <= o <= 15, 1 <= x <= 15; SHD off (init_affine's default).  Enqueue only. */
+int asm_simd_ed_affine_batch_async(asm_handle* h, const asm_batch* b, int gap_threshold, int af_threshold, int x, int o, int e,
+                                   int32_t* d_ed);
 /* bit_vec_filter_avx(read planes, ref planes, min(m, 256), max_error) (LEAP_SIMD/SHD.h:17-18, SHD.cpp:241-322):
  * d_pass[i] = 1 when the pair survives the shifted-Hamming-distance filter, 0 when it is rejected.  max_error in
  * [0, 16].  Enqueue only. */

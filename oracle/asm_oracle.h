@@ -100,6 +100,10 @@ int orc_simd_ed_batch(int64_t n, const char* reads, const uint32_t* read_off, co
 
 /* SHD on the pair's 2-bit planes: bit_vec_filter_avx(read0, read1, ref0, ref1, min(m,256), max_error)
  * (GASMA/benchmark/LEAP_SIMD/SHD.cpp:95-143,241-322; popcount.cpp:44-76,78-110).  pass[i] in {0,1}. */
+/* SIMD_ED affine mode, clean (every pair from init_affine's tables): ed[i] = get_ED() if the pair passes, else -1 */
+int orc_simd_ed_affine_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
+                             int gap_t, int af_t, int x, int o, int ext, int32_t* ed, uint8_t* pass);
+
 int orc_shd_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
                   int max_error, int32_t* pass);
 

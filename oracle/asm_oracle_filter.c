@@ -248,3 +248,73 @@ int orc_simd_ed_batch(int64_t n, const char* reads, const uint32_t* read_off, co
     }
     return 0;
 }
+
+/* SIMD_ED in affine mode (init_affine(gap_t, af_t, ED_GLOBAL, x, o, e) / load_reads / calculate_masks / reset_affine /
+ * run_affine / check_pass / get_ED, SIMD_ED.cpp:435-616,744-753), CLEAN: every pair starts from the tables init_affine leaves
+ * (-2 everywhere, start[mid][0] = 0).  The reference as run re-uses the tables of the pair before — run_affine writes I_pos,
+ * D_pos and end only where its conditions hold, reset_affine touches none of them — so its verdicts depend on everything the
+ * object has seen; equal to this function for the first pair after init_affine, which is how the pin drives it
+ * (oracle/ref_harness_simd.cpp: init_affine before every pair).  SHD is off (init_affine's default).
+ * ed[i] = get_ED() = converge_ED when the pair passes (1000000, reset_affine's value, for a pair that reaches the end at e = 0:
+ * run_affine returns before converge_ED is written, :509-514), -1 when it does not. */
+#define SIMD_AF_MAX 512
+int orc_simd_ed_affine_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
+                             int gap_t, int af_t, int x, int o, int ext, int32_t* ed, uint8_t* pass) {
+    if (gap_t < 1 || gap_t > SIMD_MAX_T || af_t < 1 || af_t > SIMD_AF_MAX || x < 1 || o < 1 || ext < 1) return -1;
+    const int lanes = 2 * gap_t + 3, mid = gap_t + 1; /* SIMD_ED.cpp:452-453 */
+    v256 hm[2 * SIMD_MAX_T + 3];
+    typedef int row_t[SIMD_AF_MAX + 1];
+    row_t* st_ = (row_t*)malloc(sizeof(row_t) * lanes * 4);
+    if (!st_) return -1;
+    row_t *start = st_, *end = st_ + lanes, *ip = st_ + 2 * lanes, *dp = st_ + 3 * lanes;
+    for (int64_t i = 0; i < n; i++) {
+        const int m = (int)(read_off[i + 1] - read_off[i]), nn = (int)(ref_off[i + 1] - ref_off[i]);
+        const int len = m > 256 ? 256 : m;
+        v256 a0, a1, b0, b1;
+        planes_of(reads + read_off[i], len, &a0, &a1);
+        planes_of(refs + ref_off[i], nn < len ? nn : len, &b0, &b1);
+        for (int l = 1; l < lanes - 1; l++) { /* calculate_masks, SIMD_ED.cpp:180-212 */
+            const int s = abs(l - mid);
+            const v256 x0 = l > mid ? avx_shr(a0, s) : a0, x1 = l > mid ? avx_shr(a1, s) : a1;
+            const v256 y0 = l < mid ? avx_shr(b0, s) : b0, y1 = l < mid ? avx_shr(b1, s) : b1;
+            hm[l] = v_or(v_xor(x0, y0), v_xor(x1, y1));
+        }
+        for (int l = 0; l < lanes; l++) /* init_affine, :467-478 */
+            for (int e = 0; e <= af_t; e++) start[l][e] = end[l][e] = ip[l][e] = dp[l][e] = -2;
+        start[mid][0] = 0;
+        int ok = 0, conv = 1000000; /* reset_affine, :483-486 */
+        end[mid][0] = count_id(hm[mid], 0, len) + start[mid][0]; /* :497-516: only the main lane has start >= 0 in ED_GLOBAL */
+        if (end[mid][0] == len) {
+            pass[i] = 1, ed[i] = conv;
+            continue;
+        }
+        for (int e = 1; e <= af_t && !ok; e++) { /* :518-614 */
+            for (int l = 1; l < lanes - 1; l++) {
+                const int top = l >= mid, bot = l <= mid;
+                if (e >= o && end[l - 1][e - o] >= 0 && end[l - 1][e - o] > (e >= ext ? ip[l - 1][e - ext] : ip[l - 1][0]))
+                    ip[l][e] = end[l - 1][e - o] + top;
+                else if (e >= ext && ip[l - 1][e - ext] >= 0)
+                    ip[l][e] = ip[l - 1][e - ext] + top;
+                if (e >= o && end[l + 1][e - o] >= 0 && end[l + 1][e - o] > (e >= ext ? dp[l + 1][e - ext] : dp[l + 1][0]))
+                    dp[l][e] = end[l + 1][e - o] + bot;
+                else if (e >= ext && dp[l + 1][e - ext] >= 0)
+                    dp[l][e] = dp[l + 1][e - ext] + bot;
+                start[l][e] = -2;
+                if (e >= x && end[l][e - x] >= 0) start[l][e] = end[l][e - x] + 1;
+                if (ip[l][e] > start[l][e]) start[l][e] = ip[l][e];
+                if (dp[l][e] > start[l][e]) start[l][e] = dp[l][e];
+                if (start[l][e] >= 0) {
+                    end[l][e] = start[l][e] + count_id(hm[l], start[l][e], len);
+                    if (end[l][e] == len) {
+                        const int diff = abs(mid - l);
+                        const int tc = e + (diff ? o + (diff - 1) * ext : 0);
+                        if (tc <= af_t && tc < conv) ok = 1, conv = tc;
+                    }
+                }
+            }
+        }
+        pass[i] = (uint8_t)ok, ed[i] = ok ? conv : -1;
+    }
+    free(st_);
+    return 0;
+}

@@ -51,6 +51,30 @@ int ref_simd_ed_batch(int64_t n, const char* reads, const uint32_t* read_off, co
     return 0;
 }
 
+// Affine mode, CLEAN: init_affine before every pair (it destroys and rebuilds the tables: -2 everywhere, start[mid][0] = 0), so
+// that no pair sees the tables of the one before; ed[i] = get_ED(), pass[i] = check_pass().
+int ref_simd_ed_affine_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
+                             int gap_t, int af_t, int x, int o, int e, int32_t* ed, uint8_t* pass) {
+    SIMD_ED* obj = new SIMD_ED;
+    std::string s1, s2;
+    for (int64_t i = 0; i < n; i++) {
+        int m = (int)(read_off[i + 1] - read_off[i]);
+        int nn = (int)(ref_off[i + 1] - ref_off[i]);
+        s1.assign(reads + read_off[i], m);
+        s2.assign(refs + ref_off[i], nn);
+        int length = m > 256 ? 256 : m;
+        obj->init_affine(gap_t, af_t, ED_GLOBAL, x, o, e);
+        obj->load_reads((char*)s1.c_str(), (char*)s2.c_str(), length);
+        obj->calculate_masks();
+        obj->reset(); /* -> reset_affine / run_affine: affine_mode is set by init_affine */
+        obj->run();
+        pass[i] = obj->check_pass() ? 1 : 0;
+        ed[i] = obj->get_ED();
+    }
+    delete obj;
+    return 0;
+}
+
 // SHD on the 2-bit planes of a pair: strings NUL-padded to 256 characters, converted with avx_convert2bit.
 int ref_shd_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
                   int max_error, int32_t* pass) {

@@ -22,6 +22,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CASES = [("filter_c1", "C1", 0, 3000), ("filter_c2", "C2", 100, 4000), ("filter_c4", "C4", 0, 3000), ("filter_c5", "C5", 200, 3000)]
 SIMD_SETTINGS = [(1, 1), (2, 0), (3, 1), (3, 0), (5, 1), (8, 0), (12, 1), (16, 1), (24, 0)]  # (ED threshold, SHD enable)
 SHD_ERRORS = [0, 1, 3, 5, 9, 16]
+# affine mode, clean (init_affine before every pair): (gap threshold, affine threshold, x, o, e)
+AFFINE_SETTINGS = [(3, 60, 2, 3, 1), (5, 40, 1, 1, 1), (8, 100, 4, 6, 2), (2, 30, 3, 5, 2), (10, 25, 1, 2, 1)]
 
 
 def main():
@@ -37,11 +39,15 @@ def main():
             out[f"ed_t{t}_shd{shd}"] = ed.astype(np.int32)
         for me in SHD_ERRORS:
             out[f"shd_e{me}"] = ref.shd(hb, me).astype(np.uint8)
+        for g, af, x, o, e in AFFINE_SETTINGS:
+            ed, ps = ref.simd_ed_affine(hb, g, af, x, o, e)
+            out[f"af_pass_g{g}_a{af}_x{x}o{o}e{e}"] = ps.astype(np.uint8)
+            out[f"af_ed_g{g}_a{af}_x{x}o{o}e{e}"] = ed.astype(np.int32)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
         index[name] = {"workload": wl, "first": first, "n": n, "inputs_sha256": inputs_sha(hb)}
         print(name, {k: float(v.mean()) for k, v in out.items() if k.startswith("pass")})
     with open(os.path.join(HERE, "filter_index.json"), "w") as fh:
-        json.dump({"cases": index, "simd_settings": SIMD_SETTINGS, "shd_errors": SHD_ERRORS,
+        json.dump({"cases": index, "simd_settings": SIMD_SETTINGS, "shd_errors": SHD_ERRORS, "affine_settings": AFFINE_SETTINGS,
                    "warm_state": list(oracle_binding.SIMD_WARM_STATE)}, fh, indent=1, sort_keys=True)
 
 

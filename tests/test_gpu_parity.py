@@ -540,6 +540,46 @@ def test_simd_ed_filter_matches_oracle(asm, engine, oracle, wl, n, ed_t, shd):
         assert ((got >= 0) == (want_pass == 1)).all()
 
 
+@pytest.mark.parametrize("wl,n", [("C1", 6000), ("C2", 12000), ("C4", 6000), ("C5", 9000), ("C3", 4000)])
+@pytest.mark.parametrize("setting", [(3, 60, 2, 3, 1), (6, 30, 1, 1, 1), (12, 120, 4, 6, 2), (2, 25, 3, 5, 2), (32, 200, 15, 15, 15),
+                                     (20, 40, 1, 2, 1)])
+def test_simd_ed_affine_filter_matches_oracle(asm, engine, oracle, wl, n, setting):
+    """SIMD_ED affine mode (init_affine / run_affine), clean: every pair from init_affine's tables; narrow and wide bands, deep
+    rings (x = o = e = 15: fewer threads per workgroup), thresholds that reject."""
+    g, af, x, o, e = setting
+    cfg, _, _ = asm.workload(wl)
+    hb = asm.generate_pairs(cfg, 43, n)
+    batch = engine.upload(hb, asm.GREEDY_CLEAN)
+    want, want_pass = oracle.simd_ed_affine(hb, g, af, x, o, e)
+    got = engine.simd_ed_affine(batch, g, af, x, o, e)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, (wl, setting, bad[:5], got[bad[:5]], want[bad[:5]])
+
+
+def test_simd_ed_affine_filter_edges_and_reference(asm, engine, oracle):
+    """Ragged and empty strings, reads beyond 256 characters, argument errors; and the compiled reference itself (run_affine with
+    init_affine before every pair) where oracle/_ref travelled with the snapshot."""
+    from tests import oracle_binding as ob
+    from tests.util import random_ragged_batch
+    hb = random_ragged_batch(asm, 9, 2000, 0, 300, err=0.2)
+    batch = engine.upload(hb, asm.GREEDY_CLEAN)
+    for g, af, x, o, e in ((4, 50, 2, 3, 1), (9, 90, 3, 4, 2)):
+        want, _ = oracle.simd_ed_affine(hb, g, af, x, o, e)
+        assert np.array_equal(engine.simd_ed_affine(batch, g, af, x, o, e), want), (g, af)
+    for bad in ((0, 10, 1, 1, 1), (33, 10, 1, 1, 1), (3, 0, 1, 1, 1), (3, 600, 1, 1, 1), (3, 10, 1, 1, 2), (3, 10, 0, 1, 1), (3, 10, 1, 16, 1)):
+        with pytest.raises(asm.AsmError):
+            engine.simd_ed_affine(batch, *bad)
+    if ob.have_reference_simd():
+        ref = ob.load_reference_simd()
+        cfg, _, _ = asm.workload("C2")
+        hb2 = asm.generate_pairs(cfg, 61, 8000)
+        b2 = engine.upload(hb2, asm.GREEDY_CLEAN)
+        r_ed, r_ps = ref.simd_ed_affine(hb2, 5, 22, 2, 3, 1)
+        got = engine.simd_ed_affine(b2, 5, 22, 2, 3, 1)
+        assert ((got >= 0) == (r_ps == 1)).all() and (got[r_ps == 1] == r_ed[r_ps == 1]).all()
+        assert 0.05 < r_ps.mean() < 0.999
+
+
 @pytest.mark.parametrize("max_error", [0, 1, 3, 5, 9, 16])
 def test_shd_filter_matches_oracle(asm, engine, oracle, max_error):
     for wl, n in (("C1", 5000), ("C2", 20000), ("C5", 12000)):
@@ -723,6 +763,8 @@ def test_per_pair_classes_of_the_reference(asm, oracle):
         assert out[1] == "leap pass %d ED %d" % (1 if leap >= 0 else 0, leap), (key, out[1])
         ed, _, ps = oracle.simd_ed(hb, 3, True, 0, (0, 0, 0))
         assert out[2] == "simd_ed pass %d ED %d" % (int(ps[0]), int(ed[0])), (key, out[2])
+        aed, aps = oracle.simd_ed_affine(hb, 3, 200, 1, 1, 1)  # SIMD_ED::init_affine(k, 200, ED_GLOBAL, x, o, e), clean
+        assert out[3] == "simd_ed affine pass %d ED %d" % (int(aps[0]), int(aed[0])), (key, out[3])
 
 
 def test_batches_may_outlive_their_engine(asm):

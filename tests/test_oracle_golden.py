@@ -212,6 +212,31 @@ def test_filter_oracle_matches_reference_goldens(asm, oracle, name):
         assert np.array_equal(ed, np.where(ps == 1, raw, -1))
     for me in FILTER_INDEX["shd_errors"]:
         assert np.array_equal(oracle.shd(hb, me), gold[f"shd_e{me}"]), (name, me)
+    for g, af, x, o, e in FILTER_INDEX["affine_settings"]:  # SIMD_ED affine mode, clean: init_affine before every pair
+        ed, ps = oracle.simd_ed_affine(hb, g, af, x, o, e)
+        key = f"g{g}_a{af}_x{x}o{o}e{e}"
+        assert np.array_equal(ps, gold["af_pass_" + key]), (name, key, "check_pass")
+        assert np.array_equal(ed, np.where(ps == 1, gold["af_ed_" + key], -1)), (name, key, "get_ED")
+
+
+def test_filter_affine_hand_cases(asm, oracle):
+    """SIMD_ED affine mode, clean: an exact pair passes with get_ED() = 1000000 (run_affine returns before converge_ED is
+    written, SIMD_ED.cpp:509-514); one substitution costs x; a deleted character costs the gap on the neighbouring lane, counted
+    twice — once as the generation in which the lane is entered, once in converge_ED's lane term (:591-594); a tight affine
+    threshold rejects what a loose one accepts."""
+    base = "ACGTTGCAAGCTTAGCCATGGATCCTAGGTACCGATATCGGCATGCAAGT"
+    sub = base[:20] + ("A" if base[20] != "A" else "C") + base[21:]
+    hb = asm.HostBatch.from_strings([(base, base), (sub, base), ("T" * 50, base)])
+    ed, ps = oracle.simd_ed_affine(hb, 3, 60, 2, 3, 1)
+    assert ed[0] == 1000000 and ps[0] == 1 and ed[1] == 2 and ps[1] == 1
+    ed2, ps2 = oracle.simd_ed_affine(hb, 3, 1, 2, 3, 1)
+    assert ps2.tolist()[:2] == [1, 0] and ed2[1] == -1
+    cfg, _, _ = asm.workload("C2")
+    big = asm.generate_pairs(cfg, 7, 3000)
+    loose, _ = oracle.simd_ed_affine(big, 5, 60, 2, 3, 1)
+    tight, _ = oracle.simd_ed_affine(big, 5, 18, 2, 3, 1)
+    assert (loose >= 0).mean() > 0.99 and 0.05 < (tight >= 0).mean() < 0.95
+    assert (tight[tight >= 0] <= 18).all()  # (not comparable with `loose` pair by pair: a lane refused for its lane term lets a later generation win)
 
 
 def test_filter_clean_mode_hand_cases(asm, oracle):

@@ -131,3 +131,20 @@ def test_input_distribution_restatement_matches_the_reference_generator(asm, ora
         reads, ro, refs, fo = oracle.reference_dataset(n, length, err, seed)
         assert np.array_equal(ro, want.read_off) and np.array_equal(fo, want.ref_off)
         assert np.array_equal(reads, want.reads) and np.array_equal(refs, want.refs)
+
+
+@pytest.mark.skipif(not oracle_binding.have_reference_simd(), reason="oracle/_ref/libasm_ref_simd.so not built")
+@pytest.mark.parametrize("setting", [(3, 60, 2, 3, 1), (6, 30, 1, 1, 1), (12, 120, 4, 6, 2), (2, 25, 3, 5, 2), (20, 40, 1, 2, 1)])
+def test_simd_ed_affine_clean_matches_the_compiled_reference(asm, oracle, setting):
+    """SIMD_ED affine mode: the oracle's clean form against the real run_affine with init_affine before every pair
+    (ragged lengths, reads longer than 256, all four workload shapes)."""
+    from tests.util import random_ragged_batch
+    ref = oracle_binding.load_reference_simd()
+    g, af, x, o, e = setting
+    batches = [asm.generate_pairs(asm.workload(wl)[0], 23, n) for wl, n in (("C2", 2500), ("C3", 1200), ("C4", 2000), ("C5", 2000))]
+    batches.append(random_ragged_batch(asm, 5, 1500, 0, 300, err=0.15))
+    for hb in batches:
+        o_ed, o_ps = oracle.simd_ed_affine(hb, g, af, x, o, e)
+        r_ed, r_ps = ref.simd_ed_affine(hb, g, af, x, o, e)
+        assert np.array_equal(o_ps, r_ps), setting
+        assert np.array_equal(o_ed, np.where(r_ps == 1, r_ed, -1)), setting

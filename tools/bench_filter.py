@@ -38,6 +38,12 @@ for T in (3, 5, 10, 16):
     ms = timed(lambda: eng.shd_filter_async(batch, T, d))
     print("shd     e=%2d                   ms %.3f pairs/s %.3e pass %.4f" % (T, ms, n / ms * 1e3, eng.to_host(d, n).mean()))
 
+# SIMD_ED affine mode, clean (init_affine(gap, af, ED_GLOBAL, x, o, e) per pair)
+for g, af, x, o, e in ((3, 60, 2, 3, 1), (3, 20, 1, 1, 1), (8, 60, 2, 3, 1), (8, 120, 4, 6, 2), (30, 60, 2, 3, 1)):
+    ms = timed(lambda: eng.simd_ed_affine_async(batch, g, af, x, o, e, d))
+    ps = (eng.to_host(d, n) >= 0).mean()
+    print("simd_ed affine gap=%2d af=%3d pen (%d,%d,%d) ms %.3f pairs/s %.3e pass %.4f" % (g, af, x, o, e, ms, n / ms * 1e3, ps))
+
 # CPU side, bounded sample
 ns = min(n, 200_000)
 hb = m.generate_pairs(cfg, 0, ns)
@@ -53,3 +59,8 @@ for T in (3,):
         print("cpu reference simd_ed T=%d shd=1: %.3e pairs/s (1 thread, incl. string conversion)" % (T, ns / dt))
         t0 = time.perf_counter(); ref.shd(hb, T); dt = time.perf_counter() - t0
         print("cpu reference shd e=%d:          %.3e pairs/s (incl. string conversion)" % (T, ns / dt))
+        small = m.generate_pairs(cfg, 0, 20_000)
+        t0 = time.perf_counter(); ref.simd_ed_affine(small, 3, 60, 2, 3, 1); dt = time.perf_counter() - t0
+        print("cpu reference simd_ed affine gap=3 af=60 (2,3,1): %.3e pairs/s (init_affine before every pair)" % (20_000 / dt))
+        t0 = time.perf_counter(); orc.simd_ed_affine(small, 3, 60, 2, 3, 1); dt = time.perf_counter() - t0
+        print("cpu port      simd_ed affine gap=3 af=60 (2,3,1): %.3e pairs/s" % (20_000 / dt))
