@@ -106,14 +106,14 @@ __global__ __launch_bounds__(SIMD_ED_THREADS) void simd_ed_kernel(const uint4* _
     const int t = threadIdx.x;
     const long i = (long)blockIdx.x * SIMD_ED_THREADS + t;
     if (i >= n) return;
-    const int m = (int)(lens[i] & 0xffffu);
+    const int m = (int)(lens[i] & 0xffffu), nn_ref = (int)(lens[i] >> 16);
     const int len = m > 64 * W64 ? 64 * W64 : m; /* main.cpp:131-132: the read's length, at most _MAX_LENGTH_ */
     VW<W64> A0, A1, B0, B1;
     load_planes<W64>(planes, n, w4, i, A0, A1, B0, B1);
     {   /* strncpy(A/B, ., length): what lies beyond is never compared, but clear it so that shifts bring in zeros only */
-        const VW<W64> lm = vw_low_ones<W64>(len);
+        const VW<W64> lm = vw_low_ones<W64>(len), lb = vw_low_ones<W64>(nn_ref < len ? nn_ref : len);
 #pragma unroll
-        for (int q = 0; q < W64; q++) A0.w[q] &= lm.w[q], A1.w[q] &= lm.w[q], B0.w[q] &= lm.w[q], B1.w[q] &= lm.w[q];
+        for (int q = 0; q < W64; q++) A0.w[q] &= lm.w[q], A1.w[q] &= lm.w[q], B0.w[q] &= lb.w[q], B1.w[q] &= lb.w[q];
     }
     VW<W64> hm[NLC];
     if (TT > 0) {
@@ -238,14 +238,15 @@ __global__ __launch_bounds__(64) void simd_ed_affine_kernel(const uint4* __restr
     __syncthreads();
     const long i = (long)blockIdx.x * TH + t;
     if (i >= n) return;
-    const int m = (int)(lens[i] & 0xffffu);
+    const int m = (int)(lens[i] & 0xffffu), nn_ref = (int)(lens[i] >> 16);
     const int len = m > 64 * W64 ? 64 * W64 : m;
     VW<W64> A0, A1, B0, B1;
     load_planes<W64>(planes, n, w4, i, A0, A1, B0, B1);
-    {
-        const VW<W64> lm = vw_low_ones<W64>(len);
+    {   /* strncpy(A/B, ., length); the reference string ends at its own length (a sequential-mode batch keeps Greedy's stale tail
+           bits beyond it) */
+        const VW<W64> lm = vw_low_ones<W64>(len), lb = vw_low_ones<W64>(nn_ref < len ? nn_ref : len);
 #pragma unroll
-        for (int q = 0; q < W64; q++) A0.w[q] &= lm.w[q], A1.w[q] &= lm.w[q], B0.w[q] &= lm.w[q], B1.w[q] &= lm.w[q];
+        for (int q = 0; q < W64; q++) A0.w[q] &= lm.w[q], A1.w[q] &= lm.w[q], B0.w[q] &= lb.w[q], B1.w[q] &= lb.w[q];
     }
     int result = -2; /* -2: still running */
     {   /* e = 0: only the main lane has a start (ED_GLOBAL, :474-477,497-516) */
@@ -397,13 +398,13 @@ __global__ __launch_bounds__(ASM_BLOCK) void shd_kernel(const uint4* __restrict_
                                                         long n, int w4, int max_error, OutMap out) {
     const long i = (long)blockIdx.x * ASM_BLOCK + threadIdx.x;
     if (i >= n) return;
-    const int m = (int)(lens[i] & 0xffffu);
+    const int m = (int)(lens[i] & 0xffffu), nn_ref = (int)(lens[i] >> 16);
     const int len = m > 64 * W64 ? 64 * W64 : m;
     VW<W64> A0, A1, B0, B1;
     load_planes<W64>(planes, n, w4, i, A0, A1, B0, B1);
-    const VW<W64> lm = vw_low_ones<W64>(len);
+    const VW<W64> lm = vw_low_ones<W64>(len), lb = vw_low_ones<W64>(nn_ref < len ? nn_ref : len); /* see simd_ed_kernel */
 #pragma unroll
-    for (int q = 0; q < W64; q++) A0.w[q] &= lm.w[q], A1.w[q] &= lm.w[q], B0.w[q] &= lm.w[q], B1.w[q] &= lm.w[q];
+    for (int q = 0; q < W64; q++) A0.w[q] &= lm.w[q], A1.w[q] &= lm.w[q], B0.w[q] &= lb.w[q], B1.w[q] &= lb.w[q];
     VW<W64> diff;
 #pragma unroll
     for (int q = 0; q < W64; q++) diff.w[q] = (A0.w[q] ^ B0.w[q]) | (A1.w[q] ^ B1.w[q]);

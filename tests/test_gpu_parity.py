@@ -556,6 +556,19 @@ def test_simd_ed_affine_filter_matches_oracle(asm, engine, oracle, wl, n, settin
     assert bad.size == 0, (wl, setting, bad[:5], got[bad[:5]], want[bad[:5]])
 
 
+def test_filters_ignore_the_stale_tails_of_sequential_batches(asm, engine, oracle):
+    """A batch packed for Greedy's sequential mode keeps the reference's stale buffer tails beyond each string's end; NW, LEAP
+    and the three filters must not see them (mixed lengths: long pairs leave long tails for the short ones that follow)."""
+    cfg, _, _ = asm.workload("C5")
+    hb = asm.generate_pairs(cfg, 3, 8000)
+    batch = engine.upload(hb, asm.GREEDY_SEQUENTIAL)
+    want, _, _ = oracle.simd_ed(hb, 5, True, asm.FILTER_CLEAN, (0, 0, 0))
+    assert np.array_equal(engine.simd_ed(batch, 5, True, asm.FILTER_CLEAN), want)
+    want, _ = oracle.simd_ed_affine(hb, 6, 80, 2, 3, 1)
+    assert np.array_equal(engine.simd_ed_affine(batch, 6, 80, 2, 3, 1), want)
+    assert np.array_equal(engine.shd_filter(batch, 5), oracle.shd(hb, 5))
+
+
 def test_simd_ed_affine_filter_edges_and_reference(asm, engine, oracle):
     """Ragged and empty strings, reads beyond 256 characters, argument errors; and the compiled reference itself (run_affine with
     init_affine before every pair) where oracle/_ref travelled with the snapshot."""

@@ -1,6 +1,6 @@
 """A longer randomized GPU-vs-oracle campaign than the test-suite affords (development tool):
 PYTHONPATH=. python tools/fuzz_gpu.py [seconds] [seed].  Every aligner, every band width 1..50, random penalties, both Greedy tail
-modes and alignment types, CIGARs, coverage; uniform, mixed and ragged lengths.  Prints one line per case; exits 1 on a mismatch."""
+modes and alignment types, CIGARs, coverage, the SIMD_ED filters (Levenshtein and affine, clean); uniform, mixed and ragged lengths.  Prints one line per case; exits 1 on a mismatch."""
 import sys, time
 import numpy as np
 import approximate_string_matching_amd as m
@@ -52,6 +52,14 @@ while time.time() - t0 < budget:
         sel = np.nonzero(gd)[0]
         res.append(("nwcigar", all(cov["nw_cigars"][i] == ncig[i] for i in range(hb.n) if len(ncig[i]) and cov["nw_cigars"][i].count("=") + cov["nw_cigars"][i].count("X") + cov["nw_cigars"][i].count("I") + cov["nw_cigars"][i].count("D") < 255)))
         res.append(("cover", bool(np.array_equal(cov["cover"][sel], wc[sel])) and cov["undetermined"] == 0))
+    if case % 4 == 0:  # filtering stage: SIMD_ED Levenshtein (clean) and affine (clean) on the same batch
+        T = int(rng.integers(1, 21))
+        want_l, _, _ = orc.simd_ed(hb, T, False, 1, (0, 0, 0))
+        res.append(("simd_ed", bool(np.array_equal(eng.simd_ed(batch, T, False, m.FILTER_CLEAN), want_l))))
+        g, af = int(rng.integers(1, 33)), int(rng.integers(1, 200))
+        ax = int(rng.integers(1, 8)); ae = int(rng.integers(1, 5)); ao = ae + int(rng.integers(0, 6))
+        want_a, _ = orc.simd_ed_affine(hb, g, af, ax, ao, ae)
+        res.append(("simd_af", bool(np.array_equal(eng.simd_ed_affine(batch, g, af, ax, ao, ae), want_a))))
     ok = all(v for _, v in res)
     bad += 0 if ok else 1
     print(f"case {case:3d} {desc:22s} n={hb.n:5d} k={k:2d} pen=({x},{o},{e}) mode={mode} semi={int(semi)}: " + " ".join(f"{a}={'ok' if v else 'FAIL'}" for a, v in res), flush=True)
