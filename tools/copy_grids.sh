@@ -1,0 +1,10 @@
+#!/bin/bash
+# After `gpurun -- bash tools/refresh_grids.sh <sha>`: copy the secondary profile files from gpurun_out/ into profiles/.
+set -e
+cd "$(dirname "$0")/.."
+G=gpurun_out/grids
+cp $G/greedy_band_grid.txt profiles/r02_greedy_band_grid.txt
+cp $G/dispatch_grid_c2.txt profiles/r02_dispatch_grid_c2.txt
+for w in C3 C4 C5; do tail -1 $G/bench_${w}_1e7.json > profiles/r02_bench_$(echo $w | tr A-Z a-z)_1e7.json; done
+cp gpurun_out/final/r02_pmc_c3.json profiles/r02_pmc_c3.json
+PYTHONPATH=$PWD python3 tools/pmc_collect.py --remix --workload C3 | tail -3
