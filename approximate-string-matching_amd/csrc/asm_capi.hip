@@ -49,7 +49,7 @@ struct asm_handle {
     bool leap_hint = true;                /* LEAP scheduled by a work hint when one is given (ASM_LEAP_HINT=0 disables) */
     bool bucketing = true;                /* group mixed-length batches by width class (ASM_BUCKET=0 disables) */
     bool wave_kernels = true;             /* wave-per-pair kernels for 6 <= k <= 31 (ASM_WAVE=0: workgroup-per-pair LDS kernels) */
-    bool persist_wide = true;             /* Greedy, k = 6..14: still one thread per pair — up to 29 lane vectors in 512 VGPR+AGPR, one
+    bool persist_wide = true;             /* Greedy, k = 6..16: still one thread per pair — up to 29 lane vectors in 512 VGPR+AGPR, one
                                              wave per SIMD (ASM_PERSIST_WIDE=0: wave per pair) */
     bool group_kernels = true;            /* Greedy, 32 <= k <= 39: sixteen threads per pair (ASM_GROUP=0: two wavefronts per pair) */
     bool nw_banded = true;                /* banded bit-parallel NW with in-kernel full-height recompute (ASM_NW_BANDED=0) */
@@ -1173,7 +1173,8 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
 #define GREEDY_WIDE_CASE(KK) \
             case KK: if (h->persist_wide && h->persist && p->k == KK) { HIPCHK(h, launch_greedy<KK>(h, b, ga, out, cig)); break; } /* else: falls through to the kernels below */
             GREEDY_WIDE_CASE(6) GREEDY_WIDE_CASE(7) GREEDY_WIDE_CASE(8) GREEDY_WIDE_CASE(9) GREEDY_WIDE_CASE(10) GREEDY_WIDE_CASE(11)
-            GREEDY_WIDE_CASE(12) GREEDY_WIDE_CASE(13) GREEDY_WIDE_CASE(14)
+            GREEDY_WIDE_CASE(12) GREEDY_WIDE_CASE(13) GREEDY_WIDE_CASE(14) GREEDY_WIDE_CASE(15) GREEDY_WIDE_CASE(16)
+            /* K = 17, 18 still win at 100 bp (0.71, 0.79 ms against 0.90) but lose at 150 bp, err 0.20 (1.67, 1.83 against 1.60) */
 #undef GREEDY_WIDE_CASE
             default:
                 if (h->group_kernels && p->k >= 32 && p->k <= 39 && (long)p->o + 110L * p->e < 16000L) {

@@ -8,7 +8,7 @@ from tests.util import greedy_defined, leap_defined, random_ragged_batch
 
 pytestmark = pytest.mark.gpu
 
-KS = [1, 2, 4, 5, 6, 7, 9, 12, 16, 21, 27, 31, 32, 33, 41, 50, 57, 63]
+KS = [1, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 16, 17, 21, 27, 31, 32, 33, 41, 50, 57, 63]
 
 
 @pytest.mark.parametrize("k", KS)
