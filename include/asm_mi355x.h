@@ -161,8 +161,10 @@ int asm_batch_pack_async(asm_handle* h, asm_batch* b);
 int asm_align_batch_async(asm_handle* h, const asm_batch* b, int aligner, const asm_params* p,
                           int32_t* d_penalties);
 /* Same as asm_align_batch_async with an optional per-pair work estimate (device int32[n], input order; NULL = none).
- * The estimate only steers scheduling — LEAP sorts each workgroup's pairs by it so that a wave's 64 pairs need about the
- * same number of generations — and never changes a result.  `_run_benchmark` passes the NW penalties of the same pairs. */
+ * The estimate only steers scheduling — LEAP sorts its pairs by it (inside each workgroup, or over the whole width class with
+ * one radix pass for long strings and general penalties) so that the pairs a wave waits for need about the same number of
+ * generations — and never changes a result.  `_run_benchmark` passes the NW penalties of the same pairs, or, where NW is
+ * not run, the Greedy penalties. */
 int asm_align_batch_hinted_async(asm_handle* h, const asm_batch* b, int aligner, const asm_params* p,
                                  const int32_t* d_work_hint, int32_t* d_penalties);
 /* Greedy with its CIGAR (hurdle_matrix::get_CIGAR, hurdle_matrix.h:613; built by _update_CIGAR :238-251 — lane switches
@@ -258,6 +260,8 @@ int asm_accuracy_async(asm_handle* h, const int32_t* d_nw, const int32_t* d_leap
                        const int32_t* d_answers, int64_t n, unsigned long long* d_counters);
 /* `_run_benchmark` for a whole resident batch in one call (benchmark_utils.h:231-259): optional re-pack of the
  * resident ASCII, then every aligner whose output pointer is non-NULL, then the counters.  Enqueue only.
+ * Order inside the call: Greedy beside the chain NW -> LEAP (LEAP scheduled by the NW penalties); with d_nw NULL and a wide
+ * band, Greedy first and LEAP scheduled by its penalties.
  * repack: 0 = use the planes as they are; 1 = pack first, in stream order; 2 = pack first, PIPELINED: the pack of this call
  * fills a second set of planes on its own stream and so overlaps the aligners of the previous call (pack waits on memory for
  * half of its time, the aligners are instruction-bound); this call's aligners wait for it.  With 2 the caller guarantees that
