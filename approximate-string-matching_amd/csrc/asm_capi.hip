@@ -23,6 +23,7 @@
 
 #include "../../include/asm_mi355x.h"
 #include "asm_kernels.h"
+#include "asm_greedy3_kernel.h"
 #include "asm_wide.h"
 #include "asm_wave.h"
 #include "asm_group.h"
@@ -46,6 +47,16 @@ struct asm_handle {
     bool persist = true;                  /* Greedy: lane-refilling persistent kernel (ASM_PERSIST=0 disables) */
     bool persist_leap = false;            /* LEAP: the plain one-pair-per-thread kernel is faster at 1e6 pairs (ASM_PERSIST_LEAP=1) */
     int refill_greedy = 8, refill_leap = 16; /* lanes that must be idle before a wave refills (tunable by env) */
+    int g3_prio = 0;                      /* ASM_GREEDY_PRIO (experiment: s_setprio turns; no effect measured) */
+    int g3_waves = 2;                     /* resident waves per SIMD of the fast Greedy kernel (ASM_GREEDY_WAVES = 1, 2, 3) */
+    int persist_waves = 0;                /* cap on the resident waves per SIMD of the persistent kernels (ASM_PERSIST_WAVES; 0 = what fits) */
+    bool greedy_fast = true;              /* Greedy, k <= 3, unit penalties, GLOBAL: the straight-line pass with integer rank keys
+                                             (asm_greedy3.h; ASM_GREEDY_FAST=0: the FP64 kernel) */
+    uint2* d_g3_table = nullptr;          /* its rank table (66 KB), built for g3_sig / g3_k; rebuilt when the probabilities change */
+    G3Sig g3_sig = {0.0, 0.0, 0.0};
+    int g3_k = 0;
+    bool g3_ok = false;
+    bool g3_attr[4] = {false, false, false, false};
     bool leap_hint = true;                /* LEAP scheduled by a work hint when one is given (ASM_LEAP_HINT=0 disables) */
     bool bucketing = true;                /* group mixed-length batches by width class (ASM_BUCKET=0 disables) */
     bool wave_kernels = true;             /* wave-per-pair kernels for 6 <= k <= 31 (ASM_WAVE=0: workgroup-per-pair LDS kernels) */
@@ -207,6 +218,7 @@ static hipError_t launch_persistent(asm_handle* h, Kern kern, int64_t n, Args...
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, ASM_BLOCK, 0);
     if (e != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
+    if (h->persist_waves > 0 && per_cu > h->persist_waves) per_cu = h->persist_waves; /* a 256-thread workgroup is one wave per SIMD */
     int64_t blocks = (int64_t)per_cu * h->num_cus;
     const int64_t need = (n + ASM_BLOCK - 1) / ASM_BLOCK;
     if (blocks > need) blocks = need;
@@ -218,11 +230,65 @@ static hipError_t launch_persistent(asm_handle* h, Kern kern, int64_t n, Args...
 static void* g_diag_buf = nullptr; /* diagnostic build only (never the shipped library): per-wave cycle stamps of the Greedy kernel */
 extern "C" void asm_diag_set_buffer(void* d) { g_diag_buf = d; }
 #endif
+/* Rank table of the straight-line Greedy kernel for these significance constants (asm_greedy3.h): built on the host with the
+ * reference build's three roundings, uploaded once per (constants, k).  False when the constants do not have the structure
+ * the integer keys need (then the FP64 kernel runs). */
+static bool g3_prepare(asm_handle* h, const GreedyArgs& ga, int K) {
+    const G3Sig sig = {ga.sig_match, ga.sig_mismatch, ga.sig_indel};
+    if (h->g3_k == K && memcmp(&sig, &h->g3_sig, sizeof(sig)) == 0) return h->g3_ok;
+    h->g3_k = K, h->g3_sig = sig, h->g3_ok = false;
+    std::vector<uint2> tab;
+    if (!g3_build_table(sig, K, tab)) return false;
+    if (!h->d_g3_table && hipMalloc((void**)&h->d_g3_table, sizeof(uint2) * G3_TABLE_ENTRIES) != hipSuccess) {
+        (void)hipGetLastError();
+        h->d_g3_table = nullptr;
+        return false;
+    }
+    /* pageable source: the copy is staged before the call returns; ordered on the stream the kernels run on */
+    if (hipMemcpyAsync(h->d_g3_table, tab.data(), sizeof(uint2) * G3_TABLE_ENTRIES, hipMemcpyHostToDevice, h->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return false;
+    h->g3_ok = true;
+    return true;
+}
+
+template <int K, int NT>
+static hipError_t launch_greedy_fast_nt(asm_handle* h, const asm_bucket& b, const GreedyArgs& ga, OutMap out, CigarSink cig) {
+    auto kern = greedy_fast_kernel<K, NT>;
+    const size_t lds = g3_lds_bytes(K, NT);
+    { /* more than 64 KB of dynamic LDS has to be asked for */
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    int64_t blocks = h->num_cus; /* one workgroup per CU (LDS) */
+    const int64_t need = (b.n + NT - 1) / NT;
+    if (blocks > need) blocks = need;
+    const G3Sig sig = {ga.sig_match, ga.sig_mismatch, ga.sig_indel};
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NT), lds, h->stream, (const uint4*)b.planes, (const uint32_t*)b.lens,
+                       (long)b.n, b.w4, sig, (const uint2*)h->d_g3_table, out, cig, h->refill_greedy, h->g3_prio);
+    return hipGetLastError();
+}
+template <int K>
+static hipError_t launch_greedy_fast(asm_handle* h, const asm_bucket& b, const GreedyArgs& ga, OutMap out, CigarSink cig) {
+    /* waves per SIMD: the waves of a SIMD are served oldest first and this kernel is a dense stream of 4-cycle vector
+     * operations, so a third wave adds little issue rate and a third more lanes to drain at the end; two is the optimum both
+     * alone (118 us against 130) and beside NW -> LEAP in asm_run_benchmark_async */
+    if (h->g3_waves == 1) return launch_greedy_fast_nt<K, 256>(h, b, ga, out, cig);
+    if (h->g3_waves == 3) return launch_greedy_fast_nt<K, 768>(h, b, ga, out, cig);
+    return launch_greedy_fast_nt<K, 512>(h, b, ga, out, cig);
+}
+
 template <int K>
 static hipError_t launch_greedy(asm_handle* h, const asm_bucket& b, const GreedyArgs& ga, OutMap out, CigarSink cig) {
 #ifdef GREEDY_DIAG
     if (cig.ops == nullptr && g_diag_buf) cig.nops = (uint8_t*)g_diag_buf;
 #endif
+    if constexpr (K <= 3) {
+        if (h->greedy_fast && h->persist && ga.x == 1 && ga.o == 1 && ga.e == 1 && !ga.semi && g3_prepare(h, ga, K))
+            return launch_greedy_fast<K>(h, b, ga, out, cig);
+    }
     if (h->persist && ga.x == 1 && ga.o == 1 && ga.e == 1 && !ga.semi)
         return launch_persistent(h, greedy_persist_kernel<K, true>, b.n, (const uint4*)b.planes, (const uint32_t*)b.lens,
                                  (long)b.n, b.w4, ga, out, cig, h->refill_greedy);
@@ -519,6 +585,10 @@ int asm_create(asm_handle** out, int device) {
     if ((env = getenv("ASM_LEAP_QUAD"))) h->leap_quad = atoi(env);
     if ((env = getenv("ASM_LEAP_SORT"))) h->leap_sort = env[0] != '0';
     if ((env = getenv("ASM_REFILL_GREEDY"))) h->refill_greedy = atoi(env);
+    if ((env = getenv("ASM_GREEDY_FAST"))) h->greedy_fast = env[0] != '0';
+    if ((env = getenv("ASM_PERSIST_WAVES"))) h->persist_waves = atoi(env);
+    if ((env = getenv("ASM_GREEDY_PRIO"))) h->g3_prio = atoi(env);
+    if ((env = getenv("ASM_GREEDY_WAVES"))) h->g3_waves = atoi(env);
     if ((env = getenv("ASM_REFILL_LEAP"))) h->refill_leap = atoi(env);
     *out = h;
     return ASM_OK;
@@ -536,6 +606,7 @@ int asm_destroy(asm_handle* h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->d_todo) (void)hipFree(h->d_todo);
+    if (h->d_g3_table) (void)hipFree(h->d_g3_table);
     for (hipEvent_t ev : h->prof_ev) (void)hipEventDestroy(ev);
     (void)hipDeviceSynchronize();
     for (char* q : h->pin_raw)

@@ -1,0 +1,143 @@
+// The persistent, lane-refilling Greedy kernel around the straight-line pass of asm_greedy3.h (narrow band, unit penalties,
+// GLOBAL: the benchmark's configuration).  Included after asm_kernels.h (WaveQueue, OutMap, CigarSink).
+#pragma once
+#include "asm_greedy3.h"
+#include "asm_kernels.h"
+
+
+#define G3_THREADS 512 /* one workgroup per CU: 8 waves = 2 per SIMD; LDS = table + 16 B per lane vector per thread */
+
+template <int NT>
+struct G3LdsStore {
+    G3V* base; /* this thread's column of the [lane][thread] array */
+    __device__ __forceinline__ void put(int j, G3V v) { base[j * NT] = v; }
+    __device__ __forceinline__ G3V get(int j) const { return base[j * NT]; }
+};
+struct G3LdsTable {
+    const uint2* t;
+    __device__ __forceinline__ uint2 get(uint32_t i) const { return t[i]; }
+};
+
+constexpr size_t g3_lds_bytes(int K, int NT) { return (size_t)G3_TABLE_ENTRIES * 8 + (size_t)(2 * K + 1) * NT * 16; }
+
+__device__ __forceinline__ G3V g3_from_uint4(uint4 q) {
+    G3V r;
+    r.lo = (g3_u64)q.x | ((g3_u64)q.y << 32), r.hi = (g3_u64)q.z | ((g3_u64)q.w << 32);
+    return r;
+}
+
+// Same contract as greedy_persist_kernel<K, true> (asm_kernels.h): wave-local static slice of the batch, lanes pull the next
+// pair when theirs is done (WaveQueue), one int32 cost per pair through OutMap, optional CIGAR rows.
+template <int K, int NT>
+__global__ __launch_bounds__(NT) void greedy_fast_kernel(const uint4* __restrict__ planes, const uint32_t* __restrict__ lens,
+                                                         long n, int w4, G3Sig sig, const uint2* __restrict__ table_g,
+                                                         OutMap out, CigarSink cig, int refill_min, int prio_mode) {
+    constexpr int NL = 2 * K + 1;
+    extern __shared__ uint4 g3_smem[];
+    uint2* const tab = reinterpret_cast<uint2*>(g3_smem);
+    G3V* const vecs = reinterpret_cast<G3V*>(g3_smem + G3_TABLE_ENTRIES / 2);
+    for (int i = threadIdx.x; i < G3_TABLE_ENTRIES / 2; i += NT) g3_smem[i] = reinterpret_cast<const uint4*>(table_g)[i];
+    __syncthreads();
+    const G3LdsTable table{tab};
+    G3LdsStore<NT> store{vecs + threadIdx.x};
+
+    G3State<K> s;
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+        s.lo[j].lo = s.lo[j].hi = s.lf[j].lo = s.lf[j].hi = 0ull;
+        s.sp[j] = -1, s.en[j] = -1, s.nsw[j] = 0, s.dst[j] = 0;
+    }
+    s.m = s.n = s.dest_lane = s.cur_lane = s.cur_col = s.cost = s.guard = 0;
+    s.finished = true;
+    long idx = -1, pair = 0;
+    int ncig = 0;
+    bool active = false, exhausted = false;
+    WaveQueue wq;
+    wq.init(n);
+#ifdef GREEDY_DIAG
+    unsigned long long dg_refill = 0, dg_step = 0, dg_iters = 0, dg_lanes = 0, dg_t0 = __builtin_amdgcn_s_memtime();
+#endif
+    // The waves of a SIMD are served oldest first, and a stream of 4-cycle vector operations leaves the younger ones little:
+    // they finish one after the other and the last runs alone.  Waves w, w+4, w+8 of a workgroup share a SIMD; taking the
+    // high priority in turns (one iteration each) lets them advance together.
+    const int prio_slot = (int)(threadIdx.x >> 8), prio_n = NT / 256;
+    int prio_it = 0;
+    for (;;) {
+        if (prio_mode == 1) {
+            if (prio_it % prio_n == prio_slot) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+            prio_it++;
+        } else if (prio_mode >= 2) { /* by the clock: every wave of the SIMD sees the same turn */
+            const int turn = (int)((__builtin_amdgcn_s_memtime() >> prio_mode) % (unsigned long long)prio_n);
+            if (turn == prio_slot) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+        }
+#ifdef GREEDY_DIAG
+        const unsigned long long dg_a = __builtin_amdgcn_s_memtime();
+#endif
+        const bool need = s.finished && !exhausted;
+        const unsigned long long need_mask = __ballot(need);
+        if (need_mask != 0ull && (__popcll(need_mask) >= refill_min || __ballot(active && !s.finished) == 0ull)) {
+            if (need && active) {
+                // ---- final hop (hurdle_matrix.h:575-590) ----
+                const int dest_col = g3_dest(s.m, s.n, s.dest_lane);
+                if (s.cur_lane != s.dest_lane || s.cur_col < dest_col) {
+                    G3V dv;
+                    if (s.dest_lane >= -K && s.dest_lane <= K) {
+                        dv = store.get(s.dest_lane + K);
+                    } else { /* destination lane outside the band: undefined in the reference, built like a band lane */
+                        const G3V A0 = g3_from_uint4(planes[((long)0 * w4) * n + idx]), A1 = g3_from_uint4(planes[((long)1 * w4) * n + idx]);
+                        const G3V B0 = g3_from_uint4(planes[((long)2 * w4) * n + idx]), B1 = g3_from_uint4(planes[((long)3 * w4) * n + idx]);
+                        const int a = s.dest_lane < 0 ? -s.dest_lane : s.dest_lane;
+                        if (s.dest_lane < 0) {
+                            const G3V x0 = g3_toward0(A0, a), x1 = g3_toward0(A1, a);
+                            dv.lo = (x0.lo ^ B0.lo) | (x1.lo ^ B1.lo), dv.hi = (x0.hi ^ B0.hi) | (x1.hi ^ B1.hi);
+                        } else {
+                            const G3V x0 = g3_toward0(B0, a), x1 = g3_toward0(B1, a);
+                            dv.lo = (x0.lo ^ A0.lo) | (x1.lo ^ A1.lo), dv.hi = (x0.hi ^ A0.hi) | (x1.hi ^ A1.hi);
+                        }
+                    }
+                    const int d = s.cur_lane - s.dest_lane;
+                    const int from = s.cur_col + g3_fwd(s.cur_lane, s.dest_lane);
+                    const bool ok = (unsigned)from < 128u && (unsigned)(dest_col - from - 1) < 128u; /* utils.h:263-270 */
+                    const int distance = ok ? g3_ones_from(dv, (uint32_t)from) - g3_ones_from(dv, (uint32_t)dest_col) : 0;
+                    s.cost += (d < 0 ? -d : d) + distance;
+                    if (cig.on()) cig.step(pair, ncig, s.cur_lane, s.dest_lane, distance); /* the hurdle count (:589) */
+                }
+                if (cig.on()) cig.finish(pair, ncig);
+                out.put(idx, s.cost);
+            }
+            const long got = wq.pull(need);
+            if (need) {
+                idx = got;
+                active = got >= 0;
+                exhausted = !active;
+            }
+            if (need && active) {
+                const G3V A0 = g3_from_uint4(planes[((long)0 * w4) * n + idx]), A1 = g3_from_uint4(planes[((long)1 * w4) * n + idx]);
+                const G3V B0 = g3_from_uint4(planes[((long)2 * w4) * n + idx]), B1 = g3_from_uint4(planes[((long)3 * w4) * n + idx]);
+                g3_setup<K>(s, A0, A1, B0, B1, lens[idx], store);
+                ncig = 0;
+                pair = out.index(idx);
+            }
+        }
+#ifdef GREEDY_DIAG
+        const unsigned long long dg_b = __builtin_amdgcn_s_memtime();
+        dg_refill += dg_b - dg_a;
+        dg_iters++;
+        dg_lanes += __popcll(__ballot(active && !s.finished));
+#endif
+        if (__ballot(active && !s.finished) == 0ull) break; /* wave-uniform: the slice is used up and every pair is done */
+        if (active && !s.finished) {
+            const G3Step st = g3_pass<K>(s, table, sig, store);
+            if (cig.on() && st.committed) cig.step(pair, ncig, st.from_lane, st.to_lane, st.run);
+        }
+#ifdef GREEDY_DIAG
+        dg_step += __builtin_amdgcn_s_memtime() - dg_b;
+#endif
+    }
+#ifdef GREEDY_DIAG
+    if ((threadIdx.x & 63) == 0 && cig.nops != nullptr && cig.ops == nullptr) { /* diag build: cig.nops doubles as the debug buffer */
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(cig.nops) + 8 * (((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+        dbg[0] = dg_refill, dbg[1] = dg_step, dbg[2] = dg_iters, dbg[3] = dg_lanes, dbg[4] = __builtin_amdgcn_s_memtime() - dg_t0;
+    }
+#endif
+}

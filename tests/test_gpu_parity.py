@@ -793,3 +793,40 @@ def test_batches_may_outlive_their_engine(asm):
     eng2 = asm.Engine(0)
     assert eng2.align(eng2.generate(cfg, 0, 100), asm.NW, params).shape == (100,)
     eng2.close()
+
+
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_fast_greedy_kernel_slow_path_and_corners(asm, engine, oracle, k):
+    """The straight-line Greedy kernel (csrc/asm_greedy3.h, k <= 3, unit penalties): solid blocks of mismatches leave the rank
+    table's domain (the FP64 slow path), 128/128 pairs hit the lane-0 destination corner, strings shorter than the band have
+    negative lane destinations, destinations outside the band rebuild their lane from the planes; with CIGARs, both tail modes."""
+    rng = np.random.default_rng(8)
+    acgt = "ACGT"
+    rnd = lambda L: "".join(acgt[i] for i in rng.integers(0, 4, L))
+    pairs = [("A" * 128, "T" * 128), ("A" * 100, "T" * 100), ("A" * 128, "A" * 128), ("", ""), ("A", ""), ("", "A"), ("A", "C"),
+             ("AC", "CA"), ("A" * 128, "A" * 120), ("A" * 120, "A" * 128), ("A" * 70 + "C" * 58, "C" * 58 + "A" * 70),
+             ("ACGTN" * 20, "ACGTN" * 20), ("A" * 64 + "T" * 64, "T" * 64 + "A" * 64)]
+    for L in (128, 127, 100, 65, 64, 63, 10, 3, 2):
+        a = rnd(L)
+        pairs += [(a, a), (a, a[1:]), (a[1:], a), (a, "T" * 40 + a[40:]), (a, rnd(L)), (a[: L // 2] + "T" * 66, a)]
+    for _ in range(3000):
+        L = int(rng.integers(1, 200))
+        a = list(rnd(L))
+        b = list(a)
+        for _ in range(int(rng.integers(0, 4))):
+            p, w = int(rng.integers(0, L)), int(rng.integers(1, 90))
+            b[p:p + w] = list(acgt[(acgt.index(c) + 1) % 4] for c in b[p:p + w])
+        if rng.random() < 0.4:
+            q = int(rng.integers(0, len(b) + 1))
+            b[q:q] = list(rnd(int(rng.integers(1, 6))))
+        pairs.append(("".join(a), "".join(b)))
+    hb = asm.HostBatch.from_strings(pairs)
+    params = asm.Params.default(k=k)
+    for mode in (asm.GREEDY_CLEAN, asm.GREEDY_SEQUENTIAL):
+        batch = engine.upload(hb, mode)
+        want, want_cig = oracle.greedy(hb, k=k, mode=1 if mode == asm.GREEDY_CLEAN else 0, cigars=True)
+        assert np.array_equal(engine.align(batch, asm.GREEDY, params), want)
+        cost, cig, _ = engine.greedy_with_cigar(batch, params, cap=128)
+        assert np.array_equal(cost, want)
+        assert cig == want_cig
+        batch.free()

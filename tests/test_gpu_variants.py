@@ -51,6 +51,9 @@ print("ok")
 
 @pytest.mark.parametrize("env", [
     {"ASM_PERSIST": "0"},
+    {"ASM_GREEDY_FAST": "0"},
+    {"ASM_GREEDY_WAVES": "3"},
+    {"ASM_GREEDY_WAVES": "1", "ASM_REFILL_GREEDY": "1"},
     {"ASM_PERSIST_LEAP": "1", "ASM_LEAP_HINT": "0"},
     {"ASM_LEAP_HINT": "0"},
     {"ASM_NW_BANDED": "0", "ASM_NW_WFA": "0"},
