@@ -27,7 +27,7 @@ ALIGNER_NAMES = {NW: "nw", LEAP: "leap", GREEDY: "greedy"}
 GREEDY_SEQUENTIAL, GREEDY_CLEAN = 0, 1
 FILTER_SEQUENTIAL, FILTER_CLEAN = 0, 1
 ALIGN_GLOBAL, ALIGN_SEMI_GLOBAL = 0, 1
-GEN_EXACT_ERRORS, GEN_PER_BASE = 0, 1
+GEN_EXACT_ERRORS, GEN_PER_BASE, GEN_UP_TO_ERRORS = 0, 1, 2
 GREEDY_MAX_LENGTH = 128
 LEAP_MAX_LENGTH = 256
 MAX_LENGTH = 512
@@ -73,6 +73,13 @@ class GenConfig(ctypes.Structure):
     def exact(cls, seed: int, length: int, err: float, mismatch_rate: float = 0.96, length_hi: Optional[int] = None):
         """Dataset(num_reads, length, err, 0.96, exact=true) — benchmark.cpp:19."""
         return cls(seed, GEN_EXACT_ERRORS, length, length_hi if length_hi is not None else length, err,
+                   mismatch_rate, 0.0, 0.0, 0.0)
+
+    @classmethod
+    def up_to(cls, seed: int, length: int, err: float, mismatch_rate: float = 0.96, length_hi: Optional[int] = None):
+        """Dataset(..., exact=false), the "lt_eq" files of GASMA/benchmark/README.md: 0 .. ceil(L*err) - 1 edit operations,
+        uniformly (benchmark_dataset.h:153-156)."""
+        return cls(seed, GEN_UP_TO_ERRORS, length, length_hi if length_hi is not None else length, err,
                    mismatch_rate, 0.0, 0.0, 0.0)
 
     @classmethod

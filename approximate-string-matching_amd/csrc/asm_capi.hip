@@ -649,7 +649,7 @@ static int check_gen(const asm_gen_config* cfg) {
     if (!cfg) return fail(nullptr, ASM_EINVAL, "generator: cfg is NULL");
     if (cfg->len_lo < 1 || cfg->len_hi < cfg->len_lo || cfg->len_hi > ASM_MAX_LENGTH)
         return fail(nullptr, ASM_EINVAL, "generator: need 1 <= len_lo <= len_hi <= ASM_MAX_LENGTH");
-    if (cfg->kind == ASM_GEN_EXACT_ERRORS) {
+    if (cfg->kind == ASM_GEN_EXACT_ERRORS || cfg->kind == ASM_GEN_UP_TO_ERRORS) {
         /* benchmark_dataset.h:192-204 */
         if (!(cfg->err >= 0.f && cfg->err <= 0.7f)) return fail(nullptr, ASM_EINVAL, "generator: err must be in [0, 0.7]");
         if (!(cfg->mismatch_rate >= 0.f && cfg->mismatch_rate <= 1.f))

@@ -50,14 +50,22 @@ ASM_HD int asm_gen_num_errors(int L, float err) {
     return (float)c < prod ? c + 1 : c;
 }
 
+// Number of edit operations of a pair: ceil(L*err), or (ASM_GEN_UP_TO_ERRORS: rand_iid(0, ceil(L*err)), benchmark_dataset.h:156)
+// uniform below it.  Drawn from the `types` stream right after the length, by both passes.
+ASM_HD int asm_gen_pair_errors(const asm_gen_config* cfg, int L, asm_rng* t) {
+    const int ne = asm_gen_num_errors(L, cfg->err);
+    if (cfg->kind != ASM_GEN_UP_TO_ERRORS) return ne;
+    return ne > 0 ? (int)t->below((uint32_t)ne) : 0;
+}
+
 // Lengths only: *m = read length, *n = ref length.
 ASM_HD void asm_gen_lengths(const asm_gen_config* cfg, uint64_t pair, int* m, int* n) {
     asm_rng t, v;
     asm_rng_for_pair(cfg->seed, pair, &t, &v);
     int L = cfg->len_lo + (int)t.below((uint32_t)(cfg->len_hi - cfg->len_lo + 1));
     int len = L;
-    if (cfg->kind == ASM_GEN_EXACT_ERRORS) {
-        int ne = asm_gen_num_errors(L, cfg->err);
+    if (cfg->kind == ASM_GEN_EXACT_ERRORS || cfg->kind == ASM_GEN_UP_TO_ERRORS) {
+        int ne = asm_gen_pair_errors(cfg, L, &t);
         for (int i = 0; i < ne; i++) {
             float u = t.unit();
             if (u <= cfg->mismatch_rate) continue;
@@ -89,10 +97,10 @@ ASM_HD void asm_gen_pair(const asm_gen_config* cfg, uint64_t pair, char* read, c
     int L = cfg->len_lo + (int)t.below((uint32_t)(cfg->len_hi - cfg->len_lo + 1));
     for (int i = 0; i < L; i++) read[i] = alphabet[v.below(4)];
     int len = 0;
-    if (cfg->kind == ASM_GEN_EXACT_ERRORS) {
+    if (cfg->kind == ASM_GEN_EXACT_ERRORS || cfg->kind == ASM_GEN_UP_TO_ERRORS) {
         for (int i = 0; i < L; i++) text[i] = read[i];
         len = L;
-        int ne = asm_gen_num_errors(L, cfg->err);
+        int ne = asm_gen_pair_errors(cfg, L, &t);
         for (int i = 0; i < ne; i++) {
             float u = t.unit();
             if (u <= cfg->mismatch_rate) { /* benchmark_dataset.h:113-120 */

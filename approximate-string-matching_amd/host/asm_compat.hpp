@@ -62,10 +62,36 @@ public:
         p_.x = x, p_.o = o, p_.e = e;
         p_.p_match = match_prob, p_.p_mismatch = mismatch_prob, p_.p_indel = indel_prob;
     }
+    // hurdle_matrix.h:473-539: the constructor that takes the pair (GASMA/main.cpp:5-9 uses it); note ITS default
+    // probabilities (0.95, 0.02, 0.03), which are not the penalty-only constructor's
+    hurdle_matrix(const char* read, const char* ref, int error, alignment_type_t type = GLOBAL, int x = 1, int o = 1, int e = 1,
+                  double match_prob = 0.95, double mismatch_prob = 0.02, double indel_prob = 0.03)
+        : hurdle_matrix(type, x, o, e, match_prob, mismatch_prob, indel_prob) {
+        reset(read, ref, error);
+    }
     void reset(const char* read, const int read_len, const char* ref, const int ref_len, int error) {
         read_.assign(read, (size_t)read_len);
         ref_.assign(ref, (size_t)ref_len);
         p_.k = error;
+    }
+    // hurdle_matrix.h:602-607: "lane %d:" and the lane's 128 hurdle bits (short hurdles flipped, :452-453), position 0 first
+    // (utils.h:37-46,78-82).  Display only — nothing is aligned here: the bits are character comparisons of the two strings
+    // as the conversion sees them (first 128 bases, codes of bit_convert.cpp:340-355, a lone object's buffer tails are zero).
+    void print() const {
+        auto code = [](const std::string& s, int i) {
+            if (i < 0 || i >= 128 || i >= (int)s.size()) return 0;
+            const char c = s[(size_t)i];
+            return c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 0;
+        };
+        for (int lane = -p_.k; lane <= p_.k; lane++) {
+            bool raw[130];
+            raw[0] = raw[129] = false; /* zeros shifted in at both ends (utils.h:200-216) */
+            for (int i = 0; i < 128; i++)
+                raw[i + 1] = lane < 0 ? code(read_, i - lane) != code(ref_, i) : code(ref_, i + lane) != code(read_, i);
+            printf("lane %d:", lane);
+            for (int i = 1; i <= 128; i++) putchar(raw[i] && (raw[i - 1] || raw[i + 1]) ? '1' : '0');
+            printf("\n");
+        }
     }
     void reset(const char* read, const char* ref, int error) { reset(read, (int)strlen(read), ref, (int)strlen(ref), error); }
     // A lone object has no batch history: tails are clean (the reference's are indeterminate for a first pair).
@@ -238,8 +264,7 @@ class Dataset {
 
 public:
     Dataset(int num_reads, int length, float error_rate, float mismatch_rate, bool exact_error_rate = true, uint64_t seed = 1) {
-        if (!exact_error_rate) throw std::runtime_error("Dataset: only exact_error_rate=true is restated");
-        cfg_.seed = seed, cfg_.kind = ASM_GEN_EXACT_ERRORS, cfg_.len_lo = cfg_.len_hi = length;
+        cfg_.seed = seed, cfg_.kind = exact_error_rate ? ASM_GEN_EXACT_ERRORS : ASM_GEN_UP_TO_ERRORS, cfg_.len_lo = cfg_.len_hi = length;
         cfg_.err = error_rate, cfg_.mismatch_rate = mismatch_rate;
         num_reads_ = num_reads;
     }
@@ -258,7 +283,8 @@ public:
     }
     std::string output() const {  // benchmark_dataset.h:242-253 file name, plus the seed
         std::string name = "simulated_" + std::to_string(num_reads_) + "_" + std::to_string(cfg_.len_lo) + "_" +
-                           std::to_string(cfg_.err) + "_eq_seed" + std::to_string(cfg_.seed) + ".seq";
+                           std::to_string(cfg_.err) + (cfg_.kind == ASM_GEN_UP_TO_ERRORS ? "_lt_eq_seed" : "_eq_seed") +
+                           std::to_string(cfg_.seed) + ".seq";
         output(name.c_str());
         return name;
     }

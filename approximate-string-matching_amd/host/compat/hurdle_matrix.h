@@ -1,0 +1,5 @@
+// Forwarding header for the reference's GASMA/hurdle_matrix.h (hurdle_matrix<T>, :20-685; int_128bit and alignment_type_t of
+// GASMA/utils.h come with it): see benchmark_utils.h.  GASMA/main.cpp compiles against it unchanged.
+#pragma once
+#include "../asm_compat.hpp"
+using namespace asm_amd;

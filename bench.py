@@ -389,7 +389,7 @@ def run(args, asm, eng, torch, dist, stream, rank, world, cfg, params, first, n,
         "dtype": "u64",
         "data": "synthetic",
         "config": {
-            "workload": f"{args.workload}: {n} pairs per GPU, len {cfg.len_lo}-{cfg.len_hi}, err {cfg.err:.2f}, "
+            "workload": f"{args.workload}: {n} pairs per GPU, len {cfg.len_lo}-{cfg.len_hi}, {edit_model(asm, cfg)}, "
                         f"k={params.k}, x=o=e={params.x},{params.o},{params.e}, aligners "
                         + "+".join(asm.ALIGNER_NAMES[a] for a in aligners) + ", greedy tails=clean",
             "pairs_per_gpu": n,
@@ -469,6 +469,37 @@ def sequential_leg(args, asm, eng, torch, dist, rank, world, cfg, params, first,
     return out
 
 
+def edit_model(asm, cfg):
+    """How the workload's pairs were mutated, for `config.workload`."""
+    if cfg.kind == asm.GEN_PER_BASE:
+        return f"per-base sub {cfg.p_sub:.5f} ins {cfg.p_ins:.6f} del {cfg.p_del:.6f}"
+    if cfg.kind == asm.GEN_UP_TO_ERRORS:
+        return f"err <= {cfg.err:.2f}"
+    return f"err {cfg.err:.2f}"
+
+
+def usable_cpus():
+    """CPUs this process may really use: its affinity mask capped by the cgroup's CPU quota (a GPU box hands a job a share of
+    its host — 16 CPUs per GPU on this pool — while the mask still lists every core; threads beyond the quota only get
+    throttled, which is what made round 2's "256 cores" leg look as if it did not scale)."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline_and_parity(asm, eng, hb, batch, params, aligners, sample, d_pen):
     """Rank 0, N=1 only: time the oracle (CPU port of the reference algorithms, bit-identical to the compiled
     reference — tests/test_oracle_vs_reference.py) on a bounded sample, single thread like the reference's own
@@ -495,7 +526,7 @@ def cpu_baseline_and_parity(asm, eng, hb, batch, params, aligners, sample, d_pen
     # the same port on every host core (OpenMP over pairs), whole batch, wall clock
     all_cores = None
     try:
-        cores = len(os.sched_getaffinity(0))
+        cores = usable_cpus()
         orc.set_threads(cores)
         w0 = time.perf_counter()
         for a in aligners:
@@ -505,7 +536,9 @@ def cpu_baseline_and_parity(asm, eng, hb, batch, params, aligners, sample, d_pen
                 orc.leap(hb, params.k, params.x, params.o, params.e)
             else:
                 orc.greedy(hb, params.k, params.x, params.o, params.e, mode=1)
-        all_cores = {"cores": cores, "value": hb.n / (time.perf_counter() - w0), "sample": f"all {hb.n} pairs, wall clock"}
+        all_cores = {"cores": cores, "value": hb.n / (time.perf_counter() - w0),
+                     "sample": f"all {hb.n} pairs, wall clock, {cores} OpenMP threads = the CPUs this job may use "
+                               f"(affinity mask {len(os.sched_getaffinity(0))}, cgroup quota applied)"}
         orc.set_threads(1)
     except Exception as exc:
         all_cores = {"error": repr(exc)}

@@ -91,6 +91,8 @@ int asm_synchronize(asm_handle* h);
 /* ---- input definition: seeded restatement of `Dataset` (benchmark_dataset.h:61-253) ---- */
 #define ASM_GEN_EXACT_ERRORS 0 /* exactly ceil(L*err) edit operations per pair (Dataset exact=true)        */
 #define ASM_GEN_PER_BASE 1     /* independent per-base substitution / insertion / deletion (SRR611076-shaped) */
+#define ASM_GEN_UP_TO_ERRORS 2 /* Dataset exact=false, the "lt_eq" files (benchmark_dataset.h:153-156,246-250): the number of
+                                  edit operations is uniform in 0 .. ceil(L*err) - 1; everything else as ASM_GEN_EXACT_ERRORS */
 typedef struct asm_gen_config {
     uint64_t seed;
     int32_t kind;

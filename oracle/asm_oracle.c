@@ -344,9 +344,15 @@ int orc_greedy_batch_typed(int64_t n, const char* reads, const uint32_t* read_of
     sig[0] = log(probs[0] / 0.25);
     sig[1] = log(probs[1] / 0.25);
     sig[2] = log(probs[2] / 2 / 0.25);
-    uint8_t* views = (uint8_t*)malloc((size_t)n * 256 + 1);
-    if (!views) return -2;
-    orc_greedy_views(n, reads, read_off, refs, ref_off, mode, views);
+    /* Clean mode: every pair sees its own zero-padded buffers, so nothing is shared between pairs and the views are built
+     * inside the parallel loop (no n x 256-byte array, no serial pre-pass: with many threads that pass was most of the time).
+     * Sequential mode: the reference's buffer chain is serial by nature; it is resolved first, the pairs then run in parallel. */
+    uint8_t* views = NULL;
+    if (mode != ORC_GREEDY_CLEAN) {
+        views = (uint8_t*)malloc((size_t)n * 256 + 1);
+        if (!views) return -2;
+        orc_greedy_views(n, reads, read_off, refs, ref_off, mode, views);
+    }
 #pragma omp parallel for schedule(static) num_threads(g_threads)
     for (int64_t i = 0; i < n; i++) {
         int m = (int)(read_off[i + 1] - read_off[i]), nn = (int)(ref_off[i + 1] - ref_off[i]);
@@ -355,8 +361,14 @@ int orc_greedy_batch_typed(int64_t n, const char* reads, const uint32_t* read_of
         cigar_t cg = {cigars ? cigars + i * cigar_stride : NULL, cigar_stride, 0};
         if (cg.buf) cg.buf[0] = 0;
         int st = 0;
-        costs[i] = greedy_pair(views + i * 256, views + i * 256 + 128, m, nn, k, x, o, e, sig, &cg, &st,
-                               alignment_type == ORC_ALIGN_SEMI_GLOBAL);
+        uint8_t local[256];
+        const uint8_t* v = views ? views + i * 256 : local;
+        if (!views) {
+            memset(local, 0, 256);
+            memcpy(local, reads + read_off[i], (size_t)m);
+            memcpy(local + 128, refs + ref_off[i], (size_t)nn);
+        }
+        costs[i] = greedy_pair(v, v + 128, m, nn, k, x, o, e, sig, &cg, &st, alignment_type == ORC_ALIGN_SEMI_GLOBAL);
         if (steps) steps[i] = st;
     }
     free(views);

@@ -113,6 +113,10 @@ int orc_shd_batch(int64_t n, const char* reads, const uint32_t* read_off, const 
  * reads: n*length bytes; refs: n*(length + ceil(length*error_rate) + 1) bytes; offsets n+1 each. */
 int orc_reference_dataset(int64_t n, int length, float error_rate, float mismatch_rate, unsigned int seed, char* reads,
                           uint32_t* read_off, char* refs, uint32_t* ref_off);
+/* the same with Dataset's exact_error_rate flag: 0 = the "lt_eq" files (number of edits uniform in 0 .. ceil(L*err) - 1,
+ * benchmark_dataset.h:153-156) that the result blocks of GASMA/benchmark/README.md were measured on */
+int orc_reference_dataset_ex(int64_t n, int length, float error_rate, float mismatch_rate, int exact, unsigned int seed,
+                             char* reads, uint32_t* read_off, char* refs, uint32_t* ref_off);
 void orc_glibc_rand_stream(unsigned int seed, int count, int32_t* out);
 
 /* number of OpenMP threads the batch entry points will use (LEAP/NW/Greedy-clean are parallel over pairs;

@@ -68,21 +68,24 @@ static uint64_t rand_iid(glibc_rand* g, uint64_t min, uint64_t max) {
     }
 }
 
-/* Dataset(num_reads, length, error_rate, mismatch_rate, exact = true).output() with srand(seed) (the reference seeds from
+/* Dataset(num_reads, length, error_rate, mismatch_rate, exact).output() with srand(seed) (the reference seeds from
  * time()): pairs in the batch layout.  reads must hold n*length bytes, refs n*(length + ceil(length*err) + 1). */
-int orc_reference_dataset(int64_t n, int length, float error_rate, float mismatch_rate, unsigned int seed, char* reads,
-                          uint32_t* read_off, char* refs, uint32_t* ref_off) {
+int orc_reference_dataset_ex(int64_t n, int length, float error_rate, float mismatch_rate, int exact, unsigned int seed,
+                             char* reads, uint32_t* read_off, char* refs, uint32_t* ref_off) {
     static const char alphabet[4] = {'A', 'C', 'G', 'T'};
     if (n < 0 || length < 1 || length > 400) return -1;
     glibc_rand g;
     glibc_srand(&g, seed);
-    const uint64_t num_errors = (uint64_t)ceil((float)length * error_rate); /* :154 — a float product */
-    char* text = (char*)malloc((size_t)length + num_errors + 2);
+    const uint64_t max_errors = (uint64_t)ceil((float)length * error_rate); /* :154 — a float product */
+    if (!exact && max_errors == 0) return -1; /* rand_iid(0, 0) divides by zero in the reference (:156) */
+    char* text = (char*)malloc((size_t)length + max_errors + 2);
     if (!text) return -2;
     uint64_t ra = 0, rb = 0;
     for (int64_t p = 0; p < n; p++) {
         char* pattern = reads + ra;
         for (int i = 0; i < length; i++) pattern[i] = alphabet[rand_iid(&g, 0, 4)]; /* :100-109 */
+        /* :153-156: exactly ceil(L * err) operations, or ("lt_eq" files, exact_error_rate = false) uniformly 0 .. ceil - 1 */
+        const uint64_t num_errors = exact ? max_errors : rand_iid(&g, 0, max_errors);
         memcpy(text, pattern, (size_t)length);
         uint64_t len = (uint64_t)length;
         for (uint64_t q = 0; q < num_errors; q++) { /* :161-181 */
@@ -108,6 +111,11 @@ int orc_reference_dataset(int64_t n, int length, float error_rate, float mismatc
     read_off[n] = (uint32_t)ra, ref_off[n] = (uint32_t)rb;
     free(text);
     return 0;
+}
+
+int orc_reference_dataset(int64_t n, int length, float error_rate, float mismatch_rate, unsigned int seed, char* reads,
+                          uint32_t* read_off, char* refs, uint32_t* ref_off) {
+    return orc_reference_dataset_ex(n, length, error_rate, mismatch_rate, 1, seed, reads, read_off, refs, ref_off);
 }
 
 /* the first `count` outputs of the emulated rand() after srand(seed) — so that a test can compare with the running libc */

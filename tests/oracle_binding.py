@@ -132,7 +132,7 @@ class Oracle:
                     out[side * 128 + s] = base_code(c)
         return out
 
-    def reference_dataset(self, n, length, err, seed, mismatch_rate=0.96):
+    def reference_dataset(self, n, length, err, seed, mismatch_rate=0.96, exact=True):
         """Pairs drawn the reference's way (oracle/asm_oracle_dataset.c: Dataset over glibc's rand() after srand(seed)) as a
         batch in the C ABI's layout (arrays are what approximate_string_matching_amd.HostBatch holds)."""
         import math
@@ -142,9 +142,9 @@ class Oracle:
         refs = np.zeros(cap, np.uint8)
         ro = np.zeros(n + 1, np.uint32)
         fo = np.zeros(n + 1, np.uint32)
-        self.lib.orc_reference_dataset.argtypes = [_i64, _i, ctypes.c_float, ctypes.c_float, ctypes.c_uint, _vp, _vp, _vp, _vp]
-        rc = self.lib.orc_reference_dataset(n, length, err, mismatch_rate, seed, reads.ctypes.data, ro.ctypes.data, refs.ctypes.data,
-                                            fo.ctypes.data)
+        self.lib.orc_reference_dataset_ex.argtypes = [_i64, _i, ctypes.c_float, ctypes.c_float, _i, ctypes.c_uint, _vp, _vp, _vp, _vp]
+        rc = self.lib.orc_reference_dataset_ex(n, length, err, mismatch_rate, 1 if exact else 0, seed, reads.ctypes.data, ro.ctypes.data,
+                                               refs.ctypes.data, fo.ctypes.data)
         assert rc == 0, rc
         return reads[:int(ro[-1])], ro, refs[:int(fo[-1])], fo
 

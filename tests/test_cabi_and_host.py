@@ -8,6 +8,8 @@ import subprocess
 import numpy as np
 import pytest
 
+ROOT = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+
 
 def test_library_exports_every_declared_symbol(asm):
     lib = asm.load_library()
@@ -140,3 +142,29 @@ def test_tail_state_advance_is_the_reference_buffer_model(asm, oracle):
         assert np.array_equal(state, want), f"after {first} pairs"
     with pytest.raises(asm.AsmError):
         asm.tail_state_advance(state, np.full(256, 7, np.uint8), 5)
+
+
+def test_the_reference_mains_compile_unmodified_against_the_compat_headers(asm):
+    """The drop-in claim on the reference's own callers: GASMA/main.cpp (hurdle_matrix's string constructor, print(), run,
+    get_CIGAR, get_cost, long_consecutive_matching_substring) and GASMA/benchmark/benchmark.cpp (Dataset, benchmark) are
+    compiled IN PLACE, unmodified, with host/compat first on the quote include path, and linked against libasm_mi355x.so
+    (`make -C oracle shim`).  Only where /root/reference exists; the executables travel to the GPU box, where
+    tests/test_gpu_parity.py::test_the_reference_mains_run_on_the_library runs them."""
+    import subprocess
+
+    if not os.path.isdir("/root/reference/GASMA"):
+        pytest.skip("the reference tree is not on this machine")
+    if not os.path.exists(asm.LIB_PATH):
+        pytest.skip("libasm_mi355x.so is not built")
+    oracle_dir = os.path.join(ROOT, "oracle")
+    for exe in ("gasma_main_on_shim", "benchmark_main_on_shim"):  # force the compile + link, whatever is there already
+        path = os.path.join(oracle_dir, "_ref", exe)
+        if os.path.exists(path):
+            os.remove(path)
+    r = subprocess.run(["make", "-s", "-C", oracle_dir, "shim"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    for exe in ("gasma_main_on_shim", "benchmark_main_on_shim"):
+        path = os.path.join(oracle_dir, "_ref", exe)
+        assert os.path.exists(path), exe
+        needed = subprocess.run(["readelf", "-d", path], capture_output=True, text=True).stdout
+        assert "libasm_mi355x.so" in needed, "the executable must run on the product library"

@@ -1,7 +1,11 @@
 """GPU parity tests proper: the HIP path (through the C ABI) against the oracle on the same seeded inputs.
 Bar: bit-exact int32 penalties.  Sizes are what the oracle finishes in seconds."""
+import os
+
 import numpy as np
 import pytest
+
+ROOT = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
 
 from tests.util import KNOWN_PAIRS, greedy_defined, random_ragged_batch
 
@@ -830,3 +834,25 @@ def test_fast_greedy_kernel_slow_path_and_corners(asm, engine, oracle, k):
         assert np.array_equal(cost, want)
         assert cig == want_cig
         batch.free()
+
+
+def test_the_reference_mains_run_on_the_library(asm):
+    """GASMA/main.cpp and GASMA/benchmark/benchmark.cpp, compiled unmodified against host/compat (oracle/Makefile `shim`, in the
+    build container) and run HERE on the GPU: the one-pair demo prints what the reference's own build of the same file printed
+    (tests/golden/gasma_main_stdout.txt: the seven lane rows, `22M1D50M1D28M`, `cost: 6`, the LCM string), and the benchmark
+    main — whose data path does not exist outside the author's machine — goes through its whole call sequence."""
+    import subprocess
+
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    demo, bench_main = os.path.join(ref_dir, "gasma_main_on_shim"), os.path.join(ref_dir, "benchmark_main_on_shim")
+    if not (os.path.exists(demo) and os.path.exists(bench_main)):
+        pytest.skip("oracle/_ref/*_on_shim are built only where /root/reference exists")
+    out = subprocess.run([demo], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    want = open(os.path.join(ROOT, "tests", "golden", "gasma_main_stdout.txt")).read()
+    assert out.stdout == want
+    out = subprocess.run([bench_main], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "Unable to open data file: /home/zhenhao/dna-align-dataset/SRR611076.data" in out.stdout
+    assert "===================== Benchmark Results =====================" in out.stdout
+    assert "Total number of alignments: 0" in out.stdout

@@ -150,6 +150,66 @@ def test_product_generator_statistics_stay_close_to_the_readme(asm, oracle, err)
     assert abs(greedy_acc - want_greedy) < 0.35 + readme_tolerance(want_greedy, n, 3.0), (err, greedy_acc, want_greedy)
 
 
+# GASMA/benchmark/README.md:21-32,44-55,67-78,90-101 (and again :121-...): result blocks on "simulated_5000000_100_<err>_lt_eq.seq",
+# i.e. Dataset(..., exact_error_rate = false): LEAP / Greedy accuracy per error rate
+README_LT_EQ = {0.05: (99.461, 99.741), 0.10: (97.642, 98.142), 0.15: (94.712, 94.004), 0.20: (92.481, 90.190)}
+# what the aligners AS COMMITTED give on that input stream (oracle = compiled reference, k = 3, x = o = e = 1; 3 x 10^5 pairs)
+LT_EQ_AS_COMMITTED = {0.05: (99.96, 97.8), 0.10: (99.58, 92.7), 0.15: (98.42, 83.9), 0.20: (97.12, 77.8)}
+
+
+@pytest.mark.parametrize("err", sorted(README_LT_EQ))
+def test_lt_eq_readme_blocks_are_characterised_not_reproduced(asm, oracle, err):
+    """The second set of published numbers in the reference tree (GASMA/benchmark/README.md, runs on the "lt_eq" datasets:
+    0 .. ceil(L*err) - 1 edits per pair).  The input stream IS reproduced exactly — oracle.reference_dataset(exact=False) is byte
+    for byte the compiled reference's generator (tests/test_oracle_vs_reference.py) — but the result blocks are not results of the
+    committed aligners: there Greedy beats LEAP at err 0.05 (99.741 vs 99.461), which the committed Greedy (pinned to the compiled
+    reference, 97.8 % on this stream) does not do at any band width or substitution rate tried (k = 1..3, mismatch rate 0.5..0.96),
+    and LEAP's 99.461 / 97.642 / 94.712 / 92.481 lie 30-80 standard errors below what the vendored LV_BAG gives (99.96 / 99.6 /
+    98.4 / 97.1).  Those runs predate the code in the tree.  Recorded as a characterisation: the values of the committed code on
+    that stream are pinned here, and the distance from the README's is asserted so that a change in either direction is noticed."""
+    n = 100_000
+    hb = asm.HostBatch(*oracle.reference_dataset(n, 100, err, seed=2000 + int(round(err * 100)), exact=False))
+    m, nn = hb.lengths()
+    edits = {0.05: 5, 0.10: 10, 0.15: 16, 0.20: 20}[err] - 1
+    assert (np.abs(nn - m) <= edits).all() and (m == 100).all()
+    nw, leap_acc, greedy_acc = _accuracy(asm, oracle, hb)
+    assert int(nw.max()) <= edits
+    have_leap, have_greedy = LT_EQ_AS_COMMITTED[err]
+    assert abs(leap_acc - have_leap) < 0.05 + readme_tolerance(have_leap, n), (err, leap_acc)
+    assert abs(greedy_acc - have_greedy) < 0.15 + readme_tolerance(have_greedy, n), (err, greedy_acc)
+    want_leap, want_greedy = README_LT_EQ[err]
+    assert leap_acc - want_leap > 10 * readme_tolerance(want_leap, n, 1.0), "the published LEAP line would now be reproduced: pin it"
+    assert want_greedy - greedy_acc > 10 * readme_tolerance(want_greedy, n, 1.0)
+
+
+def test_product_generator_up_to_mode(asm, oracle):
+    """ASM_GEN_UP_TO_ERRORS (Dataset exact = false): 0 .. ceil(L*err) - 1 edits, uniformly; same edit mix as the exact mode."""
+    n = 60_000
+    hb = asm.generate_pairs(asm.GenConfig.up_to(9, 100, 0.10), 0, n)
+    ex = asm.generate_pairs(asm.GenConfig.exact(9, 100, 0.10), 0, n)
+    m, nn = hb.lengths()
+    assert (m == 100).all() and (np.abs(nn - m) <= 9).all()
+    oracle.set_threads(min(8, os.cpu_count() or 1))
+    try:
+        nw, nw_ex = oracle.nw(hb), oracle.nw(ex)
+    finally:
+        oracle.set_threads(1)
+    assert int(nw.max()) <= 9 and int(nw_ex.max()) <= 10
+    # a tenth of the pairs has no edit at all (and a substitution writes the old base one time in four: 0.1 / (1 - 0.24) are at
+    # distance 0), and the mean distance is about half the exact mode's
+    assert abs(float((nw == 0).mean()) - 0.1 / (1 - 0.96 * 0.25)) < 0.01
+    assert 0.40 < nw.mean() / nw_ex.mean() < 0.50
+    # same stream on the reference's generator: distribution of the distances agrees within sampling noise
+    rb = asm.HostBatch(*oracle.reference_dataset(n, 100, 0.10, seed=77, exact=False))
+    oracle.set_threads(min(8, os.cpu_count() or 1))
+    try:
+        nw_ref = oracle.nw(rb)
+    finally:
+        oracle.set_threads(1)
+    h1, h2 = np.bincount(nw, minlength=11) / n, np.bincount(nw_ref, minlength=11) / n
+    assert np.abs(h1 - h2).max() < 0.01
+
+
 def test_srr_shaped_line_is_a_model_not_a_pin(asm, oracle):
     """README.md:69-90 (real reads SRR611076: LEAP 89.5 %, Greedy 92.7 %) cannot be reproduced from the three per-base rates it
     quotes: the file is not in the reference tree, and independent per-base events at those rates make pairs that k = 3 LEAP

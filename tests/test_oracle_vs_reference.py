@@ -125,12 +125,13 @@ def test_input_distribution_restatement_matches_the_reference_generator(asm, ora
     if not os.path.exists(ob.REF_DATASET):
         pytest.skip("oracle/_ref/ref_dataset is built only where /root/reference exists")
     for seed, n, length, err in ((777, 3000, 100, 0.15), (5, 2000, 100, 0.05), (123456, 1500, 150, 0.20), (99, 1000, 64, 0.10)):
-        path = tmp_path / f"ref_{seed}.seq"
-        subprocess.check_call([ob.REF_DATASET, str(seed), str(n), str(length), str(err), str(path)])
-        want = asm.HostBatch.read_seq_file(str(path))
-        reads, ro, refs, fo = oracle.reference_dataset(n, length, err, seed)
-        assert np.array_equal(ro, want.read_off) and np.array_equal(fo, want.ref_off)
-        assert np.array_equal(reads, want.reads) and np.array_equal(refs, want.refs)
+        for exact in (True, False):  # False: the "lt_eq" files (benchmark_dataset.h:153-156), 0 .. ceil(L*err) - 1 edits per pair
+            path = tmp_path / f"ref_{seed}_{int(exact)}.seq"
+            subprocess.check_call([ob.REF_DATASET, str(seed), str(n), str(length), str(err), str(path), "1" if exact else "0"])
+            want = asm.HostBatch.read_seq_file(str(path))
+            reads, ro, refs, fo = oracle.reference_dataset(n, length, err, seed, exact=exact)
+            assert np.array_equal(ro, want.read_off) and np.array_equal(fo, want.ref_off)
+            assert np.array_equal(reads, want.reads) and np.array_equal(refs, want.refs)
 
 
 @pytest.mark.skipif(not oracle_binding.have_reference_simd(), reason="oracle/_ref/libasm_ref_simd.so not built")
