@@ -126,6 +126,19 @@ static hipError_t pool_alloc(asm_handle* h, void** p, size_t bytes) {
     return e;
 }
 
+/* hipMalloc for the scratch blocks that do not come from the pool (traceback cells, sort scratch, todo lists, ...): when the
+ * device is full, the idle blocks of the pool (up to 24 GiB) are what is in the way — give them back and try once more. */
+static hipError_t big_malloc(asm_handle* h, void** p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess && h && !h->pool_idle.empty()) {
+        (void)hipGetLastError();
+        (void)hipDeviceSynchronize(); /* idle blocks may still be read by queued work */
+        pool_release_idle(h);
+        e = hipMalloc(p, bytes);
+    }
+    return e;
+}
+
 static void pool_free(asm_handle* h, void* p) {
     if (!p) return;
     if (!h || !h->pooling) {
@@ -193,6 +206,16 @@ struct asm_reference {
 };
 
 static thread_local std::string g_err;
+/* handles that exist: a batch remembers the handle whose pool its device blocks came from, and may be freed through another
+ * handle, or after its own is gone */
+static std::mutex g_live_mu;
+static std::vector<asm_handle*> g_live_handles;
+static bool handle_is_live(asm_handle* h) {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    for (asm_handle* q : g_live_handles)
+        if (q == h) return true;
+    return false;
+}
 
 static int fail(asm_handle* h, int code, const std::string& msg) {
     g_err = msg;
@@ -239,7 +262,7 @@ static bool g3_prepare(asm_handle* h, const GreedyArgs& ga, int K) {
     h->g3_k = K, h->g3_sig = sig, h->g3_ok = false;
     std::vector<uint2> tab;
     if (!g3_build_table(sig, K, tab)) return false;
-    if (!h->d_g3_table && hipMalloc((void**)&h->d_g3_table, sizeof(uint2) * G3_TABLE_ENTRIES) != hipSuccess) {
+    if (!h->d_g3_table && big_malloc(h, (void**)&h->d_g3_table, sizeof(uint2) * G3_TABLE_ENTRIES) != hipSuccess) {
         (void)hipGetLastError();
         h->d_g3_table = nullptr;
         return false;
@@ -353,7 +376,7 @@ static int launch_nw_wfa(asm_handle* h, const asm_bucket& b, const asm_params* p
     if (h->todo_cap < words) {
         if (h->d_todo) (void)hipFree(h->d_todo);
         h->d_todo = nullptr, h->todo_cap = 0;
-        HIPCHK(h, hipMalloc((void**)&h->d_todo, sizeof(uint32_t) * words));
+        HIPCHK(h, big_malloc(h, (void**)&h->d_todo, sizeof(uint32_t) * words));
         h->todo_cap = words;
     }
     uint32_t* const list_a = h->d_todo;                 /* [0] = count, [1..] = pair slots */
@@ -411,7 +434,7 @@ static int ensure_todo(asm_handle* h, size_t n) {
     if (h->todo_cap < n + 1) {
         if (h->d_todo) (void)hipFree(h->d_todo);
         h->d_todo = nullptr, h->todo_cap = 0;
-        HIPCHK(h, hipMalloc((void**)&h->d_todo, sizeof(uint32_t) * (n + 1)));
+        HIPCHK(h, big_malloc(h, (void**)&h->d_todo, sizeof(uint32_t) * (n + 1)));
         h->todo_cap = n + 1;
     }
     return ASM_OK;
@@ -428,7 +451,7 @@ static int cover_full_matrix(asm_handle* h, const asm_bucket& b, const asm_param
     chunk = chunk < 64 ? 64 : chunk;
     chunk = chunk > count ? count : chunk;
     uint32_t* d_scratch = nullptr;
-    HIPCHK(h, hipMalloc((void**)&d_scratch, per_pair * (size_t)chunk));
+    HIPCHK(h, big_malloc(h, (void**)&d_scratch, per_pair * (size_t)chunk));
     int rc = ASM_OK;
     for (int64_t lo = 0; lo < count && !rc; lo += chunk) {
         const int64_t c = count - lo < chunk ? count - lo : chunk;
@@ -467,8 +490,8 @@ static int cover_bucket(asm_handle* h, const asm_bucket& b, const asm_params* p,
     if (rc) return rc;
     Cell* d_trace = nullptr;
     int32_t* d_band = nullptr;
-    HIPCHK(h, hipMalloc((void**)&d_trace, (size_t)cols * (size_t)slice * sizeof(Cell)));
-    if (hipMalloc((void**)&d_band, sizeof(int32_t) * (size_t)slice) != hipSuccess) {
+    HIPCHK(h, big_malloc(h, (void**)&d_trace, (size_t)cols * (size_t)slice * sizeof(Cell)));
+    if (big_malloc(h, (void**)&d_band, sizeof(int32_t) * (size_t)slice) != hipSuccess) {
         (void)hipFree(d_trace);
         return fail(h, ASM_ENOMEM, "asm_coverage: hipMalloc failed");
     }
@@ -590,12 +613,24 @@ int asm_create(asm_handle** out, int device) {
     if ((env = getenv("ASM_GREEDY_PRIO"))) h->g3_prio = atoi(env);
     if ((env = getenv("ASM_GREEDY_WAVES"))) h->g3_waves = atoi(env);
     if ((env = getenv("ASM_REFILL_LEAP"))) h->refill_leap = atoi(env);
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        g_live_handles.push_back(h);
+    }
     *out = h;
     return ASM_OK;
 }
 
 int asm_destroy(asm_handle* h) {
     if (!h) return ASM_OK;
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        for (size_t i = 0; i < g_live_handles.size(); i++)
+            if (g_live_handles[i] == h) {
+                g_live_handles.erase(g_live_handles.begin() + (long)i);
+                break;
+            }
+    }
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
@@ -622,19 +657,30 @@ int asm_destroy(asm_handle* h) {
 
 const char* asm_last_error(const asm_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
 
+/* The pool recycles freed blocks in the order of the handle's stream.  When that stream changes, work queued on the old one may
+ * still use blocks that are already back in the pool: drain the old stream once, so that whatever is handed out under the new
+ * stream is really free. */
+static int switch_stream(asm_handle* h, hipStream_t next) {
+    if (next == h->stream) return ASM_OK;
+    if (h->pooling && !h->pool_idle.empty()) {
+        HIPCHK(h, hipSetDevice(h->device));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    h->stream = next;
+    return ASM_OK;
+}
+
 int asm_set_stream(asm_handle* h, void* hip_stream) {
     if (!h) return fail(nullptr, ASM_EINVAL, "asm_set_stream: NULL handle");
     /* NULL is HIP's legacy default stream (what torch.cuda.current_stream().cuda_stream is outside a stream context): work is
      * then ordered with everything else the caller enqueues there.  The handle's own stream is non-blocking — it never
      * synchronises with the legacy stream — so it is only restored on request (asm_reset_stream). */
-    h->stream = (hipStream_t)hip_stream;
-    return ASM_OK;
+    return switch_stream(h, (hipStream_t)hip_stream);
 }
 
 int asm_reset_stream(asm_handle* h) {
     if (!h) return fail(nullptr, ASM_EINVAL, "asm_reset_stream: NULL handle");
-    h->stream = h->own_stream;
-    return ASM_OK;
+    return switch_stream(h, h->own_stream);
 }
 
 int asm_synchronize(asm_handle* h) {
@@ -1029,7 +1075,7 @@ int asm_reference_upload(asm_handle* h, const char* text, size_t len, asm_refere
     HIPCHK(h, hipSetDevice(h->device));
     asm_reference* r = new asm_reference;
     r->len = len;
-    if (hipMalloc((void**)&r->d_text, len + 16) != hipSuccess) {
+    if (big_malloc(h, (void**)&r->d_text, len + 16) != hipSuccess) {
         delete r;
         return fail(h, ASM_ENOMEM, "asm_reference_upload: hipMalloc failed");
     }
@@ -1158,14 +1204,17 @@ int asm_batch_resolve_tails(asm_handle* h, asm_batch* b, const uint8_t* state) {
 
 int asm_batch_free(asm_handle* h, asm_batch* b) {
     if (!b) return ASM_OK;
-    if (!h) { /* the handle is gone (asm_destroy released every block of its pool, this batch's included): only the record is left */
+    /* The device blocks belong to the pool of the handle that created the batch (b->owner), whichever handle is named here:
+     * they go back THERE.  If that handle is gone, asm_destroy has released every block of its pool, this batch's included, and
+     * only the record is left (h may then be NULL). */
+    (void)h;
+    if (!handle_is_live(b->owner)) {
         for (hipEvent_t ev : b->ev_consumed)
             if (ev) (void)hipEventDestroy(ev);
         delete b;
         return ASM_OK;
     }
-    (void)hipSetDevice(h->device);
-    b->owner = h;
+    (void)hipSetDevice(b->owner->device);
     batch_release(b);
     return ASM_OK;
 }
@@ -1304,7 +1353,7 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
                 if (h->sort_cap < need) {
                     if (h->d_sort) (void)hipFree(h->d_sort);
                     h->d_sort = nullptr, h->sort_cap = 0;
-                    HIPCHK(h, hipMalloc((void**)&h->d_sort, need));
+                    HIPCHK(h, big_malloc(h, (void**)&h->d_sort, need));
                     h->sort_cap = need;
                 }
                 uint32_t* const d_idx = (uint32_t*)h->d_sort;
@@ -1571,10 +1620,10 @@ int asm_simd_ed_batch_async(asm_handle* h, const asm_batch* b, int ed_threshold,
         rc = fail(h, ASM_ENODEVICE, std::string(#call) + " failed"); \
         break;                                                     \
     }
-        TRY(hipMalloc((void**)&d_a, sizeof(int32_t) * (size_t)n));
-        TRY(hipMalloc((void**)&d_b, sizeof(int32_t) * (size_t)n));
+        TRY(big_malloc(h, (void**)&d_a, sizeof(int32_t) * (size_t)n));
+        TRY(big_malloc(h, (void**)&d_b, sizeof(int32_t) * (size_t)n));
         TRY(hipcub::DeviceScan::InclusiveScan(nullptr, tmp_bytes, d_a, d_b, LastSetter(), (int)n, h->stream));
-        TRY(hipMalloc(&d_tmp, tmp_bytes + 16));
+        TRY(big_malloc(h, &d_tmp, tmp_bytes + 16));
         hipLaunchKernelGGL(simd_ed_setter_kernel, g, t, 0, h->stream, (const int32_t*)d_ed, n, d_a);
         TRY(hipcub::DeviceScan::InclusiveScan(d_tmp, tmp_bytes, d_a, d_b, LastSetter(), (int)n, h->stream));
         TRY(hipMemcpyAsync(&last_setter, d_b + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
@@ -2053,7 +2102,11 @@ int asm_stream_seq_file(asm_handle* h, const char* path, const asm_params* p, in
     std::thread reader;
 
     auto cleanup = [&]() {
-        stop = true;
+        {   /* under the mutex: the reader evaluates its wait predicate under it, and a store between its test and its block
+               would otherwise be a lost wake-up */
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
         cv.notify_all();
         if (reader.joinable()) reader.join();
         (void)hipDeviceSynchronize();
@@ -2098,6 +2151,15 @@ int asm_stream_seq_file(asm_handle* h, const char* path, const asm_params* p, in
     }
     STREAM_TRY(pool_alloc(h, (void**)&d_cnt, 32));
     STREAM_TRY(hipMemsetAsync(d_cnt, 0, 32, h->stream));
+    /* d_raw comes from the pool, whose blocks are recycled in the order of the HANDLE's stream: kernels still queued there may
+     * read the block's previous life.  The copy stream is non-blocking and would not wait for them by itself. */
+    if (!rc) {
+        hipEvent_t ev_pool = nullptr;
+        STREAM_TRY(hipEventCreateWithFlags(&ev_pool, hipEventDisableTiming));
+        STREAM_TRY(hipEventRecord(ev_pool, h->stream));
+        STREAM_TRY(hipStreamWaitEvent(copy_stream, ev_pool, 0));
+        if (ev_pool) (void)hipEventDestroy(ev_pool);
+    }
     if (rc) {
         cleanup();
         return rc;
@@ -2148,6 +2210,8 @@ int asm_stream_seq_file(asm_handle* h, const char* path, const asm_params* p, in
                 eof = true;
             }
             if (!eof) {
+                /* (the two bytes the reader may append above stay inside the slot: reads stop at cap - 8 and every slot was
+                 * allocated with cap + 64) */
                 if (boundary == 0 && have >= s.cap - 8) failed = true; /* one pair longer than a whole chunk */
                 carry.assign(s.buf + boundary, s.buf + have);
             }
@@ -2202,7 +2266,8 @@ int asm_stream_seq_file(asm_handle* h, const char* path, const asm_params* p, in
         last = s.last;
         const int64_t n = s.pairs;
         if (n > 0) {
-            if (n > pen_cap || !d_pen[0][0]) { /* staging sized by the largest chunk so far (chunks hold about the same number of pairs) */
+            if (n > pen_cap) { /* staging sized by the largest chunk so far (chunks hold about the same number of pairs); pen_cap = 0
+                                  until the first chunk — not "is the NW buffer there", which a mask without NW never satisfies */
                 harvest(q ^ 1);
                 const int64_t cap = n + n / 8 + 1024;
                 for (int qq = 0; qq < 2 && !rc; qq++)

@@ -10,7 +10,10 @@
 //                                                                        (hurdle_matrix reset/run/get_cost/get_CIGAR, LV, SIMD_ED)
 //   asm-bench --leap-simd ERROR [--shd 0|1] [--batch-run N] < pairs      the LEAP_SIMD stdin filter driver
 //                                                                        (GASMA/benchmark/LEAP_SIMD/main.cpp:52-101)
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -25,6 +28,25 @@
 // The multi-GPU form of the harness loop: pairs are independent, so rank r owns a contiguous shard of the seeded stream,
 // generated on its own device; the only exchange is the sum of {total_tests, nw_correct, LEAP_correct, greedy_correct}
 // (benchmark_utils.h:238,249-255) — 32 bytes, one ncclAllReduce over the direct xGMI links.
+// A rank that fails before the collective must not leave the others blocked in it: every rank arrives at a host-side barrier
+// first, and the all-reduce is enqueued only if nobody has failed by then.
+struct RankBarrier {
+    std::mutex mu;
+    std::condition_variable cv;
+    int waiting = 0, generation = 0, parties;
+    explicit RankBarrier(int n) : parties(n) {}
+    void arrive_and_wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        const int gen = generation;
+        if (++waiting == parties) {
+            waiting = 0, generation++;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return generation != gen; });
+        }
+    }
+};
+
 static int run_multi_gpu(int gpus, long n, int len, float err, uint64_t seed, const asm_params& p, int mode, int steps) {
     int have = asm_device_count();
     if (have < gpus) {
@@ -42,6 +64,11 @@ static int run_multi_gpu(int gpus, long n, int len, float err, uint64_t seed, co
     std::vector<unsigned long long> sums((size_t)gpus * 4, 0ull);
     std::vector<int> rcs((size_t)gpus, 0);
     std::vector<std::thread> ranks;
+    std::atomic<int> failed(0);
+    RankBarrier barrier(gpus);
+    std::vector<uint8_t> summaries((size_t)gpus * 256, 0); /* sequential mode: what each shard does to the reference's buffers */
+    const char* inject = getenv("ASM_BENCH_FAIL_RANK"); /* test hook: this rank reports a failure before the collective */
+    const int fail_rank = inject ? atoi(inject) : -1;
     asm_gen_config cfg{};
     cfg.seed = seed, cfg.kind = ASM_GEN_EXACT_ERRORS, cfg.len_lo = cfg.len_hi = len, cfg.err = err, cfg.mismatch_rate = 0.96f;
     for (int r = 0; r < gpus; r++)
@@ -55,6 +82,20 @@ static int run_multi_gpu(int gpus, long n, int len, float err, uint64_t seed, co
             if (!rc && hipStreamCreate(&stream) != hipSuccess) rc = ASM_ENODEVICE;
             if (!rc) rc = asm_set_stream(h, stream); /* the library's kernels and the collective on ONE stream */
             if (!rc) rc = asm_batch_generate(h, &cfg, (int64_t)r * n, n, mode, &b);
+            /* Greedy's sequential mode is the reference run over the WHOLE stream: the shards are chained exactly as bench.py and
+             * the Python ranks do it — every shard's 256-byte summary is exchanged (here through host memory, the ranks being
+             * threads), each rank folds the shards before its own and resolves its tails from that state (include/asm_mi355x.h) */
+            if (mode == ASM_GREEDY_SEQUENTIAL) {
+                if (!rc) rc = asm_batch_tail_summary(h, b, &summaries[(size_t)r * 256]);
+                if (rc) failed = 1;
+                barrier.arrive_and_wait();
+                if (!rc && !failed) {
+                    uint8_t state[256];
+                    memset(state, 0, sizeof state);
+                    for (int q = 0; q < r && !rc; q++) rc = asm_tail_state_advance(state, &summaries[(size_t)q * 256], n);
+                    if (!rc) rc = asm_batch_resolve_tails(h, b, state);
+                }
+            }
             for (auto& d : d_pen)
                 if (!rc) rc = asm_device_malloc(h, sizeof(int32_t) * (size_t)n, &d);
             if (!rc) rc = asm_device_malloc(h, 32, &d_cnt);
@@ -65,6 +106,10 @@ static int run_multi_gpu(int gpus, long n, int len, float err, uint64_t seed, co
             for (int s = 0; s < steps && !rc; s++)
                 rc = asm_run_benchmark_async(h, b, &p, 1, (int32_t*)d_pen[0], (int32_t*)d_pen[1], (int32_t*)d_pen[2], nullptr,
                                              (unsigned long long*)d_cnt);
+            if (r == fail_rank) rc = ASM_EINVAL;
+            if (rc) failed = 1;
+            barrier.arrive_and_wait(); /* nobody enters the collective unless everybody can */
+            if (!rc && failed) rc = ASM_ENODEVICE;
             if (!rc && ncclAllReduce(d_cnt, d_cnt, 4, ncclUint64, ncclSum, comm[(size_t)r], stream) != ncclSuccess) rc = ASM_ENODEVICE;
             if (!rc) rc = asm_synchronize(h);
             ms[(size_t)r] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -78,7 +123,10 @@ static int run_multi_gpu(int gpus, long n, int len, float err, uint64_t seed, co
             rcs[(size_t)r] = rc;
         });
     for (auto& t : ranks) t.join();
-    for (int r = 0; r < gpus; r++) ncclCommDestroy(comm[(size_t)r]);
+    for (int r = 0; r < gpus; r++) {
+        if (failed) ncclCommAbort(comm[(size_t)r]);
+        else ncclCommDestroy(comm[(size_t)r]);
+    }
     double worst = 0;
     for (int r = 0; r < gpus; r++) {
         if (rcs[(size_t)r]) {

@@ -145,8 +145,9 @@ int asm_batch_from_hits(asm_handle* h, const asm_reference* ref, int64_t n, cons
 int asm_batch_tail_summary(asm_handle* h, const asm_batch* b, uint8_t* summary /* [256] */);
 int asm_tail_state_advance(uint8_t* state /* [256], in/out */, const uint8_t* summary /* [256] */, int64_t n_pairs);
 int asm_batch_resolve_tails(asm_handle* h, asm_batch* b, const uint8_t* state /* [256] or NULL */);
-int asm_batch_free(asm_handle* h, asm_batch* b); /* h = the handle that made it; NULL after that handle was destroyed (its
-                                                    device memory went with the handle: only the record is freed) */
+int asm_batch_free(asm_handle* h, asm_batch* b); /* the device blocks go back to the pool of the handle that MADE the batch,
+                                                    whichever live handle (or NULL) is named here; once that handle has been
+                                                    destroyed its device memory went with it and only the record is freed */
 int64_t asm_batch_size(const asm_batch* b);
 int asm_batch_max_length(const asm_batch* b);
 /* Copies the batch's ASCII form back to the host (buffers sized by the caller from the offsets). */

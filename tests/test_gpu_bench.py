@@ -97,3 +97,23 @@ def test_cxx_harness_multi_gpu_mode_and_streaming(asm, oracle, tmp_path):
     got = [float(v) for v in re.findall(r"\| (\d+\.\d+) %", r.stdout)]
     assert got[:3] == [100.0, round(100.0 * float((leap == nw).mean()), 3), round(100.0 * float((greedy == nw).mean()), 3)], r.stdout
     assert "[Streamed] %d pairs" % n in r.stdout
+
+
+def test_cxx_harness_sequential_mode_and_a_failing_rank(asm, oracle):
+    """asm-bench --gpus N in its default mode (sequential: the reference as run — the shards are chained through their 256-byte
+    tail summaries before the timed loop, as bench.py's ranks do) prints the oracle's sequential-mode Greedy percentage; and a
+    rank that fails before the collective makes the program exit non-zero instead of leaving the other ranks blocked in it."""
+    import re
+
+    exe = os.path.join(ROOT, "approximate-string-matching_amd", "asm-bench")
+    n, steps = 20000, 2
+    r = subprocess.run([exe, "--gpus", "1", "--n", str(n), "--steps", str(steps)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    cfg, _, params = asm.workload("C2")
+    hb = asm.generate_pairs(cfg, 0, n)
+    nw, leap, greedy = oracle.nw(hb), oracle.leap(hb, params.k), oracle.greedy(hb, params.k, mode=0)
+    got = [float(v) for v in re.findall(r"\| (\d+\.\d+) %", r.stdout)]
+    assert got == [100.0, round(100.0 * float((leap == nw).mean()), 3), round(100.0 * float((greedy == nw).mean()), 3)], r.stdout
+    r = subprocess.run([exe, "--gpus", "1", "--n", "5000", "--steps", "1"], env=dict(os.environ, ASM_BENCH_FAIL_RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "rank 0 failed" in r.stderr

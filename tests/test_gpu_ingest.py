@@ -65,6 +65,9 @@ def test_streamed_file_equals_the_whole_file_run(asm, engine, oracle, tmp_path, 
     cut = n // 3 + 7
     part, st2 = engine.stream_seq_file(path, params, asm.GREEDY_CLEAN, aligners=(asm.GREEDY,), chunk_bytes=chunk, max_pairs=cut)
     assert st2.pairs == cut and np.array_equal(part[asm.GREEDY], oracle.greedy(hb.slice(0, cut), params.k, mode=1))
+    # without NW in the mask (the C3 shape: LEAP + Greedy): the staging buffers of the two other aligners alone
+    two, st4 = engine.stream_seq_file(path, params, asm.GREEDY_SEQUENTIAL, aligners=(asm.LEAP, asm.GREEDY), chunk_bytes=chunk)
+    assert st4.pairs == n and np.array_equal(two[asm.GREEDY], greedy) and np.array_equal(two[asm.LEAP][ok_leap], leap[ok_leap])
     # an answers file (benchmark_utils.h:358-368) shorter than the input: the rest falls back to the NW penalty
     answers = nw[: n // 2].copy()
     answers[::5] += 1
