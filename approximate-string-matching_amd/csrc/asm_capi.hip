@@ -63,6 +63,7 @@ struct asm_handle {
     bool persist_wide = true;             /* Greedy, k = 6..16: still one thread per pair — up to 29 lane vectors in 512 VGPR+AGPR, one
                                              wave per SIMD (ASM_PERSIST_WIDE=0: wave per pair) */
     bool group_kernels = true;            /* Greedy, 32 <= k <= 39: sixteen threads per pair (ASM_GROUP=0: two wavefronts per pair) */
+    bool nw_bylen = true;                 /* unit-cost NW on mixed-length batches: workgroup-local sort by length (ASM_NW_BYLEN=0) */
     bool nw_banded = true;                /* banded bit-parallel NW with in-kernel full-height recompute (ASM_NW_BANDED=0) */
     int leap_quad = 3;                    /* LEAP, wide band: four threads per pair (ASM_LEAP_QUAD bit 0: unit penalties, bit 1: general) */
     bool leap_band = true;                /* LEAP, wide band: thread per pair with the band in LDS (ASM_LEAP_BAND=0: wave per pair) */
@@ -168,6 +169,7 @@ struct asm_bucket {
     uint4* planes = nullptr;    /* uint4[4][w4][n], inside asm_batch::d_planes */
     uint32_t* lens = nullptr;   /* uint32[n],       inside asm_batch::d_lens   */
     uint32_t* order = nullptr;  /* bucket slot -> pair index; null when the batch is one bucket in input order */
+    bool mixed = false;         /* one of several width classes of a mixed-length batch */
 };
 
 struct asm_batch {
@@ -601,6 +603,7 @@ int asm_create(asm_handle** out, int device) {
     if ((env = getenv("ASM_POOL"))) h->pooling = env[0] != '0';
     if ((env = getenv("ASM_PERSIST_WIDE"))) h->persist_wide = env[0] != '0';
     if ((env = getenv("ASM_NW_BANDED"))) h->nw_banded = env[0] != '0';
+    if ((env = getenv("ASM_NW_BYLEN"))) h->nw_bylen = env[0] != '0';
     if ((env = getenv("ASM_NW_WFA"))) h->nw_wfa = env[0] != '0';
     if ((env = getenv("ASM_NW_WFA2"))) h->nw_wfa_second = atoi(env);
     if ((env = getenv("ASM_RING_BYTES"))) h->ring_bytes = atoi(env);
@@ -916,6 +919,7 @@ static int batch_finish(asm_handle* h, asm_batch* b) {
             b->bk[q].planes = b->d_planes + b->pb.plane_off[q];
             b->bk[q].lens = b->d_lens + b->pb.start[q];
             b->bk[q].order = b->d_order ? b->d_order + b->pb.start[q] : nullptr;
+            b->bk[q].mixed = bucketed;
         }
 #undef TRY
         if (b->greedy_mode == ASM_GREEDY_SEQUENTIAL) rc = batch_resolve_tails(h, b, nullptr, nullptr, true);
@@ -1437,14 +1441,24 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
                     hipLaunchKernelGGL(nw_unit_kernel<6>, g, t, 0, h->stream, planes, lens, n, b.w4, out);
                 else
                     hipLaunchKernelGGL(nw_unit_kernel<8>, g, t, 0, h->stream, planes, lens, n, b.w4, out);
+            } else if (b.mixed && h->nw_bylen) { /* a width class of a mixed-length batch: workgroup-local sort by length */
+                const dim3 g((unsigned)((b.n + NW_SORT_PAIRS - 1) / NW_SORT_PAIRS));
+                if (b.w4 == 1)
+                    hipLaunchKernelGGL((nw_banded_kernel<4, 32, true>), g, t, 0, h->stream, planes, lens, n, b.w4, out);
+                else if (b.w4 == 2)
+                    hipLaunchKernelGGL((nw_banded_kernel<8, 64, true>), g, t, 0, h->stream, planes, lens, n, b.w4, out);
+                else if (b.w4 == 3)
+                    hipLaunchKernelGGL((nw_banded_kernel<12, 64, true>), g, t, 0, h->stream, planes, lens, n, b.w4, out);
+                else
+                    hipLaunchKernelGGL((nw_banded_kernel<16, 64, true>), g, t, 0, h->stream, planes, lens, n, b.w4, out);
             } else if (b.w4 == 1)
-                hipLaunchKernelGGL((nw_banded_kernel<4, 32>), g, t, 0, h->stream, planes, lens, n, b.w4, out);
+                hipLaunchKernelGGL((nw_banded_kernel<4, 32, false>), g, t, 0, h->stream, planes, lens, n, b.w4, out);
             else if (b.w4 == 2)
-                hipLaunchKernelGGL((nw_banded_kernel<8, 64>), g, t, 0, h->stream, planes, lens, n, b.w4, out);
+                hipLaunchKernelGGL((nw_banded_kernel<8, 64, false>), g, t, 0, h->stream, planes, lens, n, b.w4, out);
             else if (b.w4 == 3)
-                hipLaunchKernelGGL((nw_banded_kernel<12, 64>), g, t, 0, h->stream, planes, lens, n, b.w4, out);
+                hipLaunchKernelGGL((nw_banded_kernel<12, 64, false>), g, t, 0, h->stream, planes, lens, n, b.w4, out);
             else
-                hipLaunchKernelGGL((nw_banded_kernel<16, 64>), g, t, 0, h->stream, planes, lens, n, b.w4, out);
+                hipLaunchKernelGGL((nw_banded_kernel<16, 64, false>), g, t, 0, h->stream, planes, lens, n, b.w4, out);
         } else {
             /* a zero penalty makes the wavefront read the generation it is writing (ring slot s - 0): plain Gotoh handles it */
             const bool positive = p->x >= 1 && p->o >= 1 && p->e >= 1;

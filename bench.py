@@ -161,6 +161,10 @@ def parse_args():
                     help="skip the separately instrumented stand-alone kernel pass (profiling runs: every launch is a timed-region launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sequential", action="store_true", help="skip the Greedy sequential-mode (reference as run) leg")
+    ap.add_argument("--extra-pairs", type=int, default=10_000_000,
+                    help="N > 1 only: TOTAL pairs of the two extra legs (BASELINE configs 4 and 5: C4 strong scaling, C5 bucketed)")
+    ap.add_argument("--extra-steps", type=int, default=5)
+    ap.add_argument("--no-extra", action="store_true", help="N > 1: skip the C4 / C5 legs")
     return ap.parse_args()
 
 
@@ -351,6 +355,13 @@ def run(args, asm, eng, torch, dist, stream, rank, world, cfg, params, first, n,
     if not args.no_sequential and asm.GREEDY in aligners:
         sequential = sequential_leg(args, asm, eng, torch, dist, rank, world, cfg, params, first, n, d_pen, coll_device, barrier)
 
+    # BASELINE.json configs 4 and 5 are multi-GPU configurations the driver's `--gpus N` run never names: after the C2
+    # weak-scaling line's timed region, every rank also runs them as STRONG scaling over a fixed total (its contiguous slice)
+    extra = None
+    if world > 1 and not args.no_extra and args.workload == "C2":
+        extra = {key: extra_leg(args, asm, eng, torch, dist, stream, rank, world, wl, coll_device, barrier)
+                 for key, wl in (("c4_strong", "C4"), ("c5_bucketed", "C5"))}
+
     coverage = None
     if rank == 0 and asm.NW in aligners and (params.x, params.o, params.e) == (1, 1, 1):
         # the harness's fourth counter (benchmark_utils.h:256-258), once, outside the timed region
@@ -407,6 +418,7 @@ def run(args, asm, eng, torch, dist, stream, rank, world, cfg, params, first, n,
                      "expected_total": (args.total_pairs if args.total_pairs else world * n) * args.steps},
         "coverage_pct": coverage,
         "sequential_mode": sequential,
+        **(extra or {}),
         "roofline": {
             "bound": "hbm",
             "kernel": dom,
@@ -429,6 +441,70 @@ def run(args, asm, eng, torch, dist, stream, rank, world, cfg, params, first, n,
     if world == 1 and not args.no_cpu_baseline:
         out.update(cpu_baseline_and_parity(asm, eng, hb, batch, params, aligners, args.cpu_sample, d_pen))
     return out
+
+
+def extra_leg(args, asm, eng, torch, dist, stream, rank, world, workload, coll_device, barrier):
+    """One more configuration of BASELINE.json in the same N-rank job: `--extra-pairs` pairs IN TOTAL (strong scaling), rank r
+    owns the contiguous slice asm.shard_bounds gives it, generated on its own GPU; step = pack + NW + LEAP + Greedy + counters as
+    in the main line; the four counters are summed over ranks by the same 32-byte all-reduce.  Mixed-length C5 goes through the
+    bucketed-by-length launch inside every rank.  Returned on every rank (the caller prints rank 0's)."""
+    cfg, _, params = asm.workload(workload)
+    total = args.extra_pairs
+    lo, hi = asm.shard_bounds(total, world, rank)
+    n = hi - lo
+    batch = eng.generate(cfg, lo, n)
+    d = [eng.malloc(4 * max(n, 1)) for _ in range(3)]
+    counters = torch.zeros(4, dtype=torch.int64, device="cuda")
+    steps = args.extra_steps
+
+    def step():
+        eng.run_benchmark_async(batch, params, d[0], d[1], d[2], counters.data_ptr(), repack=1)
+
+    step()
+    barrier()
+    counters.zero_()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ar0 = time.perf_counter()
+    if coll_device.type == "cuda":
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record(stream)
+        dist.all_reduce(counters)
+        ev[1].record(stream)
+        torch.cuda.synchronize()
+        allreduce_ms = ev[0].elapsed_time(ev[1])
+    else:  # gloo rehearsal: through the host
+        stream.synchronize()
+        ar0 = time.perf_counter()
+        host = counters.cpu()
+        dist.all_reduce(host)
+        counters.copy_(host)
+        allreduce_ms = (time.perf_counter() - ar0) * 1e3
+    barrier()
+    mine = time.perf_counter() - t0
+    tt = torch.tensor([mine], dtype=torch.float64, device=coll_device)
+    parts = [torch.empty_like(tt) for _ in range(world)]
+    dist.all_gather(parts, tt)
+    elapsed = max(float(p.item()) for p in parts)
+    cnt = counters.cpu().numpy()
+    for ptr in d:
+        eng.free(ptr)
+    batch.free()
+    return {
+        "workload": f"{workload}: {total} pairs in total over {world} ranks (strong), len {cfg.len_lo}-{cfg.len_hi}, "
+                    f"{edit_model(asm, cfg)}, k={params.k}" + (", bucketed by length inside each rank" if cfg.len_hi > cfg.len_lo else ""),
+        "scaling": "strong",
+        "steps": steps,
+        "ms_per_step": elapsed / steps * 1e3,
+        "pairs_per_s": total * steps / elapsed,
+        "ms_per_step_per_rank": [float(p.item()) / steps * 1e3 for p in parts],
+        "allreduce_ms": allreduce_ms,
+        "counters": {"total": int(cnt[0]), "nw_ok": int(cnt[1]), "leap_ok": int(cnt[2]), "greedy_ok": int(cnt[3]),
+                     "expected_total": total * steps},
+        "counters_as_expected": bool(int(cnt[0]) == total * steps and int(cnt[1]) == total * steps),
+    }
 
 
 def sequential_leg(args, asm, eng, torch, dist, rank, world, cfg, params, first, n, d_pen, coll_device, barrier):

@@ -34,14 +34,28 @@ def _expected_counts(asm, oracle, first, n):
 
 def test_self_started_ranks_share_one_stream_with_the_collective(asm, oracle):
     n, steps = 20000, 3
+    extra_total, extra_steps = 30001, 2   # an odd total: the strong split gives the ranks different shard sizes
     out = _bench({"ASM_DIST_BACKEND": "gloo"}, "--gpus", "2", "--pairs", str(n), "--steps", str(steps), "--warmup", "1",
-                 "--cpu-sample", "20000", "--no-cpu-baseline")
+                 "--cpu-sample", "20000", "--no-cpu-baseline", "--extra-pairs", str(extra_total), "--extra-steps", str(extra_steps))
     assert out["n_gpus"] == 2 and len(out["ms_per_step_per_rank"]) == 2 and out["allreduce_ms"] is not None
     want = steps * (_expected_counts(asm, oracle, 0, n) + _expected_counts(asm, oracle, n, n))   # rank r owns [r*n, (r+1)*n)
     c = out["counters"]
     assert [c["total"], c["nw_ok"], c["leap_ok"], c["greedy_ok"]] == want.tolist()
     assert c["total"] == c["expected_total"]
     assert out["sequential_mode"]["ms_per_step"] > 0
+    # BASELINE configs 4 and 5 ride along in the same N-rank job: C4 strong scaling, C5 bucketed by length (bench.extra_leg)
+    for key, wl in (("c4_strong", "C4"), ("c5_bucketed", "C5")):
+        leg = out[key]
+        assert leg["scaling"] == "strong" and leg["steps"] == extra_steps and len(leg["ms_per_step_per_rank"]) == 2
+        assert leg["ms_per_step"] > 0 and leg["pairs_per_s"] > 0 and leg["allreduce_ms"] is not None
+        assert leg["counters_as_expected"] and leg["counters"]["total"] == extra_total * extra_steps
+        cfg, _, params = asm.workload(wl)
+        hb = asm.generate_pairs(cfg, 0, extra_total)   # the shards are contiguous slices of this stream
+        nw, leap, greedy = oracle.nw(hb), oracle.leap(hb, params.k), oracle.greedy(hb, params.k, mode=1)
+        assert leg["counters"]["greedy_ok"] == extra_steps * int((greedy == nw).sum())
+        ok = np.maximum(*hb.lengths()) <= 256   # LEAP beyond 256 bases is undefined in the reference
+        if ok.all():
+            assert leg["counters"]["leap_ok"] == extra_steps * int((leap == nw).sum())
 
 
 def test_single_rank_through_rccl_and_sequential_leg(asm, oracle):

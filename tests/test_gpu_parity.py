@@ -231,8 +231,10 @@ def test_empty_batch_and_errors(asm, engine):
 
 
 def test_device_generator_matches_host_generator(asm, engine):
-    for name, n in (("C2", 5000), ("C4", 5000), ("C5", 3000), ("C3", 2000)):
-        cfg, _, _ = asm.workload(name)
+    cases = [(name, asm.workload(name)[0], n) for name, n in (("C2", 5000), ("C4", 5000), ("C5", 3000), ("C3", 2000))]
+    cases.append(("lt_eq", asm.GenConfig.up_to(31, 100, 0.15), 4000))   # Dataset exact = false (benchmark_dataset.h:153-156)
+    cases.append(("lt_eq mixed", asm.GenConfig.up_to(32, 40, 0.20, length_hi=180), 3000))
+    for name, cfg, n in cases:
         hb = asm.generate_pairs(cfg, 123, n)
         db = engine.generate(cfg, 123, n).download()
         assert np.array_equal(hb.read_off, db.read_off) and np.array_equal(hb.ref_off, db.ref_off), name
