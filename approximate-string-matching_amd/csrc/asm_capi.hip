@@ -769,17 +769,18 @@ static void batch_release(asm_batch* b) {
 
 static hipError_t launch_pack(asm_handle* h, const asm_batch* b, const uint4* tails, uint4* planes, uint32_t* lens,
                               const PackBuckets& pb, const uint32_t* pos) {
-    const dim3 grid((unsigned)((b->n + ASM_BLOCK - 1) / ASM_BLOCK)), block(ASM_BLOCK);
+    const dim3 grid((unsigned)((b->n + PACK_BLOCK - 1) / PACK_BLOCK)), block(PACK_BLOCK);
     int wmax = 1;
     for (int q = 0; q < pb.nb; q++) wmax = pb.w4[q] > wmax ? pb.w4[q] : wmax;
     // LDS staging: room for 256 strings of the batch's longest length (+ alignment slack), at least one string
-    size_t stage = (size_t)ASM_BLOCK * (size_t)(b->maxlen + 4) + 64;
+    size_t stage = (size_t)PACK_BLOCK * (size_t)(b->maxlen + 4) + 64;
     stage = (stage + 1023) & ~(size_t)1023;
     if (stage > PACK_SB) stage = PACK_SB;
     if (stage < 2048) stage = 2048;
-    const size_t lds = stage + 64; /* + the over-read slack of pack_convert */
+    const size_t lds = stage + 256; /* + the over-read slack of pack_convert and the 64 bytes of padding behind the staged data
+                                       (pack_pad; the swizzle stays inside a 128-byte row) */
 #define PACK_LAUNCH(W)                                                                                                    \
-    if (stage <= 7 * ASM_BLOCK * 16)                                                                                      \
+    if (stage <= 7 * PACK_BLOCK * 16)                                                                                      \
         hipLaunchKernelGGL((pack_kernel<W, 7>), grid, block, lds, h->stream, b->d_reads, b->d_read_off, b->d_refs,        \
                            b->d_ref_off, tails, planes, lens, (long)b->n, pb, pos, (uint32_t)stage);                      \
     else                                                                                                                  \

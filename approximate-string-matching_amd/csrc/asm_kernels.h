@@ -35,6 +35,9 @@
 // one LDS bank.  Long batches are staged in rounds of whole pairs that fit the buffer.
 // --------------------------------------------------------------------------------------------------------
 #define PACK_SB (48 * 1024)
+#ifndef PACK_BLOCK
+#define PACK_BLOCK 256 /* pairs (threads) per pack workgroup; 128 and 64 measured: C2 59.6 and 60.8 us against 58.7, C5 1.93 and 1.71 ms against 1.28 */
+#endif
 
 // Length buckets of a batch (mixed-length batches are grouped by the number of 128-position granules their longer
 // string needs, so that every kernel launch works on pairs of one width class).  Bucket b holds the pairs at slots
@@ -113,8 +116,86 @@ ASM_DEV void pack_convert(const uint32_t* sb, uint32_t b0, int len, int w4, int 
 }
 
 
+// The same conversion for strings that hold nothing but A, C, G, T — what the aligners are fed almost always.  Then bits 1-2 of
+// a character ARE its code (A 00, C 01, T 10, G 11 -> plane0 = bit1 ^ bit2, plane1 = bit2) and the per-byte "is it exactly the
+// base it could be" test of pack_convert (a SWAR zero-byte test and two masks per dword: half of its instructions) shrinks to
+// accumulating canon ^ ch over the string.  Returns that accumulated difference: non-zero = some byte was not a base (or the
+// string's last dwords ran into bytes that are not), and the caller converts the string again with pack_convert, whose stores
+// overwrite these.  The staging buffer is padded with 'A's behind the last string so that running past a string's end into
+// its neighbour — or into the padding — never raises the flag by itself.
+template <int W4>
+ASM_DEV uint32_t pack_convert_acgt(const uint32_t* sb, uint32_t b0, int len, int w4, int s, const uint4* __restrict__ tails,
+                                   long n, long pair, uint4* __restrict__ bplanes, long bn, long local) {
+    const int a0 = (int)(b0 >> 2);
+    const uint32_t sh = (b0 & 3u) * 8u;
+    uint32_t bad = 0u;
+#pragma unroll
+    for (int g = 0; g < W4; g++) {
+        if (g < w4) {
+            uint32_t q0[4] = {0u, 0u, 0u, 0u}, q1[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const int cbase = g * 128 + w * 32;
+                if (cbase < len) {
+                    uint32_t d[9];
+#pragma unroll
+                    for (int q = 0; q < 9; q++) {
+                        const int a = a0 + (cbase >> 2) + q;
+                        d[q] = sb[a ^ (((a >> 5) & 7) << 2)];
+                    }
+                    uint32_t g0 = 0u, g1 = 0u;
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const uint32_t ch = __builtin_amdgcn_alignbit(d[q + 1], d[q], sh);
+                        const uint32_t half = ch >> 1, quarter = ch >> 2;
+                        const uint32_t canon = __builtin_amdgcn_perm(0u, 0x47544341u, half & 0x03030303u);
+                        bad |= canon ^ ch;
+                        const uint32_t f0 = (half ^ quarter) & 0x01010101u, f1 = quarter & 0x01010101u;
+                        if ((q & 1) == 0) {
+                            g0 = __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false);
+                            g1 = __builtin_amdgcn_udot4(f1, 0x08040201u, 0u, false);
+                        } else {
+                            q0[w] |= __builtin_amdgcn_udot4(f0, 0x80402010u, g0, false) << (8 * (q >> 1));
+                            q1[w] |= __builtin_amdgcn_udot4(f1, 0x80402010u, g1, false) << (8 * (q >> 1));
+                        }
+                    }
+                    const int keep = len - cbase; /* > 0 */
+                    const uint32_t km = keep >= 32 ? ~0u : ((1u << keep) - 1u);
+                    q0[w] &= km, q1[w] &= km;
+                }
+            }
+            uint4 v0 = make_uint4(q0[0], q0[1], q0[2], q0[3]);
+            uint4 v1 = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+            if (tails != nullptr && g == 0) {
+                const uint4 t0 = tails[(long)(2 * s) * n + pair], t1 = tails[(long)(2 * s + 1) * n + pair];
+                v0.x |= t0.x, v0.y |= t0.y, v0.z |= t0.z, v0.w |= t0.w;
+                v1.x |= t1.x, v1.y |= t1.y, v1.z |= t1.z, v1.w |= t1.w;
+            }
+            bplanes[((long)(2 * s) * w4 + g) * bn + local] = v0;
+            bplanes[((long)(2 * s + 1) * w4 + g) * bn + local] = v1;
+        }
+    }
+    return bad;
+}
+
+// 64 bytes of 'A' behind the staged vectors (`vecs` 16-byte vectors were staged; swizzled like everything else).  Written by
+// the threads that do not store the last vectors' neighbours: no overlap with the staging stores, same barrier.
+ASM_DEV void pack_pad(uint4* s_buf, int vecs, int t) {
+    if (t < 4) {
+        const int a = 4 * (vecs + t);
+        s_buf[(a ^ (((a >> 5) & 7) << 2)) >> 2] = make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
+    }
+}
+
+template <int W4>
+ASM_DEV void pack_convert_any(const uint32_t* sb, uint32_t b0, int len, int w4, int s, const uint4* __restrict__ tails, long n,
+                              long pair, uint4* __restrict__ bplanes, long bn, long local) {
+    if (pack_convert_acgt<W4>(sb, b0, len, w4, s, tails, n, pair, bplanes, bn, local) != 0u)
+        pack_convert<W4>(sb, b0, len, w4, s, tails, n, pair, bplanes, bn, local);
+}
+
 template <int W4, int NV> /* NV = staging vectors (16 B) per thread the fast path may hold in registers */
-__global__ __launch_bounds__(ASM_BLOCK) void pack_kernel(const char* __restrict__ reads,
+__global__ __launch_bounds__(PACK_BLOCK) void pack_kernel(const char* __restrict__ reads,
                                                          const uint32_t* __restrict__ read_off,
                                                          const char* __restrict__ refs,
                                                          const uint32_t* __restrict__ ref_off,
@@ -126,10 +207,10 @@ __global__ __launch_bounds__(ASM_BLOCK) void pack_kernel(const char* __restrict_
     // staging buffer sized by the host from the batch's longest string: short reads leave room for more resident
     // workgroups per CU (5 at 100 bp instead of 3), which is what hides the HBM latency of the staging loads
     extern __shared__ uint4 s_buf[];
-    __shared__ uint32_t s_off[2][ASM_BLOCK + 1];
+    __shared__ uint32_t s_off[2][PACK_BLOCK + 1];
     const int t = threadIdx.x;
-    const long p0 = (long)blockIdx.x * ASM_BLOCK;
-    const int np = (n - p0) < ASM_BLOCK ? (int)(n - p0) : ASM_BLOCK;
+    const long p0 = (long)blockIdx.x * PACK_BLOCK;
+    const int np = (n - p0) < PACK_BLOCK ? (int)(n - p0) : PACK_BLOCK;
     const uint32_t* sb = reinterpret_cast<const uint32_t*>(s_buf);
     // where this thread's pair lives in the bucketed layout
     const long slot = (t < np) ? (pos ? (long)pos[p0 + t] : p0 + t) : 0;
@@ -144,42 +225,44 @@ __global__ __launch_bounds__(ASM_BLOCK) void pack_kernel(const char* __restrict_
     // both offset tables up front: one global round trip instead of two
     s_off[0][t] = read_off[p0 + (t < np ? t : np)];
     s_off[1][t] = ref_off[p0 + (t < np ? t : np)];
-    if (t == 0) s_off[0][ASM_BLOCK] = read_off[p0 + np], s_off[1][ASM_BLOCK] = ref_off[p0 + np];
+    if (t == 0) s_off[0][PACK_BLOCK] = read_off[p0 + np], s_off[1][PACK_BLOCK] = ref_off[p0 + np];
     __syncthreads();
     const uint32_t oA0 = s_off[0][t], oA1 = s_off[0][t + 1], oB0 = s_off[1][t], oB1 = s_off[1][t + 1];
     const uint32_t baseA = s_off[0][0] & ~15u, baseB = s_off[1][0] & ~15u;
-    const uint32_t bytesA = s_off[0][ASM_BLOCK] - baseA, bytesB = s_off[1][ASM_BLOCK] - baseB;
+    const uint32_t bytesA = s_off[0][PACK_BLOCK] - baseA, bytesB = s_off[1][PACK_BLOCK] - baseB;
     if (t < np) lens[slot] = (oA1 - oA0) | ((oB1 - oB0) << 16);
 
-    if (bytesA <= stage_bytes && bytesB <= stage_bytes && bytesB <= (uint32_t)(NV * ASM_BLOCK * 16)) {
+    if (bytesA <= stage_bytes && bytesB <= stage_bytes && bytesB <= (uint32_t)(NV * PACK_BLOCK * 16)) {
         // Fast path (every string of the block fits the buffer): the refs' bytes are fetched into registers while the
         // reads are being converted, so their HBM latency hides behind the SWAR work.
         const int nvA = (int)((bytesA + 15u) >> 4), nvB = (int)((bytesB + 15u) >> 4);
         const uint4* srcA = reinterpret_cast<const uint4*>(reads + baseA);
         const uint4* srcB = reinterpret_cast<const uint4*>(refs + baseB);
-        for (int v = t; v < nvA; v += ASM_BLOCK) {
+        for (int v = t; v < nvA; v += PACK_BLOCK) {
             const int a = 4 * v;
             s_buf[(a ^ (((a >> 5) & 7) << 2)) >> 2] = srcA[v];
         }
+        pack_pad(s_buf, nvA, t);
         uint4 rb[NV];
 #pragma unroll
         for (int q = 0; q < NV; q++) {
-            const int v = t + q * ASM_BLOCK;
+            const int v = t + q * PACK_BLOCK;
             rb[q] = v < nvB ? srcB[v] : make_uint4(0u, 0u, 0u, 0u);
         }
         __syncthreads();
-        if (t < np) pack_convert<W4>(sb, oA0 - baseA, (int)(oA1 - oA0), w4, 0, tails, n, p0 + t, bplanes, bn, local);
+        if (t < np) pack_convert_any<W4>(sb, oA0 - baseA, (int)(oA1 - oA0), w4, 0, tails, n, p0 + t, bplanes, bn, local);
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < NV; q++) {
-            const int v = t + q * ASM_BLOCK;
+            const int v = t + q * PACK_BLOCK;
             if (v < nvB) {
                 const int a = 4 * v;
                 s_buf[(a ^ (((a >> 5) & 7) << 2)) >> 2] = rb[q];
             }
         }
+        pack_pad(s_buf, nvB, t);
         __syncthreads();
-        if (t < np) pack_convert<W4>(sb, oB0 - baseB, (int)(oB1 - oB0), w4, 1, tails, n, p0 + t, bplanes, bn, local);
+        if (t < np) pack_convert_any<W4>(sb, oB0 - baseB, (int)(oB1 - oB0), w4, 1, tails, n, p0 + t, bplanes, bn, local);
         return;
     }
     // General path: stage whole pairs in rounds that fit the buffer.
@@ -197,12 +280,13 @@ __global__ __launch_bounds__(ASM_BLOCK) void pack_kernel(const char* __restrict_
             const uint32_t hi = s_off[s][pe];
             const int nvec = (int)((hi - base + 15u) >> 4);
             const uint4* src = reinterpret_cast<const uint4*>(str + base);
-            for (int v = t; v < nvec; v += ASM_BLOCK) {
+            for (int v = t; v < nvec; v += PACK_BLOCK) {
                 const int a = 4 * v;
                 s_buf[(a ^ (((a >> 5) & 7) << 2)) >> 2] = src[v];
             }
+            pack_pad(s_buf, nvec, t);
             __syncthreads();
-            if (t >= ps && t < pe) pack_convert<W4>(sb, o0 - base, len, w4, s, tails, n, p0 + t, bplanes, bn, local);
+            if (t >= ps && t < pe) pack_convert_any<W4>(sb, o0 - base, len, w4, s, tails, n, p0 + t, bplanes, bn, local);
             ps = pe;
         }
     }
