@@ -12,6 +12,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <fcntl.h>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -1944,25 +1945,111 @@ static NlScan scan_newlines(const char* p, size_t len, int threads) {
     return tot;
 }
 
-static void parallel_pread(int fd, char* dst, size_t len, off_t off, int threads, std::atomic<bool>& failed) {
-    if (threads < 1) threads = 1;
-    std::vector<std::thread> pool;
-    const size_t step = ((len + (size_t)threads - 1) / (size_t)threads + 4095) & ~(size_t)4095;
-    auto work = [&](int t) {
-        size_t a = (size_t)t * step;
-        const size_t b = a + step < len ? a + step : len;
-        while (a < b) {
-            const ssize_t got = pread(fd, dst + a, b - a, off + (off_t)a);
-            if (got <= 0) {
-                failed = true;
-                return;
-            }
-            a += (size_t)got;
+/* Worker threads that live as long as one asm_stream_seq_file call: a chunk is read AND scanned for newlines by the same
+ * workers in one go (each its own slice: pread into the pinned buffer, then memchr over the bytes it has just written).
+ * Round 2 started 2 x 8 threads per chunk — half a millisecond of every 64 MB chunk — and passed over the data twice. */
+class StreamWorkers {
+    std::vector<std::thread> threads_;
+    std::mutex mu_;
+    std::condition_variable cv_work_, cv_done_;
+    std::function<void(int)> job_;
+    int generation_ = 0, pending_ = 0;
+    bool quit_ = false;
+
+public:
+    explicit StreamWorkers(int n) {
+        for (int t = 0; t < n; t++)
+            threads_.emplace_back([this, t]() {
+                int seen = 0;
+                for (;;) {
+                    std::function<void(int)> job;
+                    {
+                        std::unique_lock<std::mutex> lk(mu_);
+                        cv_work_.wait(lk, [&] { return quit_ || generation_ != seen; });
+                        if (quit_) return;
+                        seen = generation_;
+                        job = job_;
+                    }
+                    job(t);
+                    {
+                        std::lock_guard<std::mutex> lk(mu_);
+                        if (--pending_ == 0) cv_done_.notify_all();
+                    }
+                }
+            });
+    }
+    int size() const { return (int)threads_.size(); }
+    void run(const std::function<void(int)>& job) { /* job(t) on every worker t; returns when all are done */
+        std::unique_lock<std::mutex> lk(mu_);
+        job_ = job;
+        pending_ = (int)threads_.size();
+        generation_++;
+        cv_work_.notify_all();
+        cv_done_.wait(lk, [&] { return pending_ == 0; });
+    }
+    ~StreamWorkers() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            quit_ = true;
         }
+        cv_work_.notify_all();
+        for (auto& th : threads_) th.join();
+    }
+};
+
+/* buf[0, head) is already there (the carry of the chunk before); reads `len` file bytes behind it and returns the newline
+ * summary of buf[0, head + len) */
+static NlScan read_and_scan(StreamWorkers& pool, int fd, char* buf, size_t head, size_t len, off_t off, std::atomic<bool>& failed) {
+    const int threads = pool.size();
+    std::vector<NlScan> part((size_t)threads + 1);
+    const size_t step = ((len + (size_t)threads - 1) / (size_t)threads + 4095) & ~(size_t)4095;
+    auto scan = [&](size_t a, size_t b) { /* newlines of buf[a, b), positions relative to buf */
+        NlScan r;
+        const char* q = buf + a;
+        const char* end = buf + (a < b ? b : a);
+        while (q < end) {
+            const char* hit = (const char*)memchr(q, '\n', (size_t)(end - q));
+            if (!hit) break;
+            r.count++, r.prev = r.last, r.last = (int64_t)(hit - buf);
+            q = hit + 1;
+        }
+        return r;
     };
-    for (int t = 1; t < threads; t++) pool.emplace_back(work, t);
-    work(0);
-    for (auto& th : pool) th.join();
+    part[0] = scan(0, head);
+    pool.run([&](int t) {
+        /* read and scan in blocks of 1 MB: the scan then finds the bytes the copy has just written still in the core's cache
+         * (scanning an 8 MB slice after reading all of it fetched every byte from DRAM a second time) */
+        const size_t a0 = (size_t)t * step, b = a0 + step < len ? a0 + step : len;
+        NlScan mine;
+        for (size_t a = a0; a < b;) {
+            const size_t blk_end = a + ((size_t)1 << 20) < b ? a + ((size_t)1 << 20) : b;
+            const size_t blk_a = a;
+            while (a < blk_end) {
+                const ssize_t got = pread(fd, buf + head + a, blk_end - a, off + (off_t)a);
+                if (got <= 0) {
+                    failed = true;
+                    return;
+                }
+                a += (size_t)got;
+            }
+            const NlScan r = scan(head + blk_a, head + blk_end);
+            if (r.count) {
+                mine.count += r.count;
+                mine.prev = r.count >= 2 ? r.prev : mine.last;
+                mine.last = r.last;
+            }
+        }
+        part[(size_t)t + 1] = mine;
+    });
+    NlScan tot;
+    for (const NlScan& r : part) {
+        if (!r.count) continue;
+        tot.count += r.count;
+        if (r.count >= 2) tot.prev = r.prev;
+        else tot.prev = tot.last; /* the segment's only newline: the one before it is the running last */
+        tot.last = r.last;
+    }
+    return tot;
 }
 
 /* A batch out of raw text already in HBM (n pairs = 2n lines, every line ending in '\n'). */
@@ -2097,7 +2184,10 @@ int asm_stream_seq_file(asm_handle* h, const char* path, const asm_params* p, in
     chunk = chunk < 4096 ? 4096 : chunk;
     if (chunk > ((size_t)1 << 30)) chunk = (size_t)1 << 30;
     const size_t slot_cap = chunk + ((size_t)4 << 20); /* + room for the carried tail and the EOF padding */
-    const int reader_threads = 8;
+    /* reader workers: one thread's page-cache copy (~5 GB/s) is far below PCIe; a GPU box gives a job 16 CPUs per GPU */
+    int reader_threads = (int)std::thread::hardware_concurrency();
+    reader_threads = reader_threads > 16 ? 16 : (reader_threads < 2 ? 2 : reader_threads);
+    if (const char* env = getenv("ASM_READER_THREADS")) reader_threads = atoi(env) > 0 ? atoi(env) : reader_threads;
     const auto t_begin = std::chrono::steady_clock::now();
 
     SeqSlot slot[3];
@@ -2183,6 +2273,7 @@ int asm_stream_seq_file(asm_handle* h, const char* path, const asm_params* p, in
     /* ---- reader: fills slots in rotation ---- */
     reader = std::thread([&]() {
         (void)hipSetDevice(h->device);
+        StreamWorkers workers(reader_threads);
         std::vector<char> carry;
         size_t file_off = 0;
         int64_t pairs_left = max_pairs > 0 ? max_pairs : INT64_MAX;
@@ -2205,12 +2296,14 @@ int asm_stream_seq_file(asm_handle* h, const char* path, const asm_params* p, in
             size_t want = chunk;
             if (file_off + want > file_bytes) want = file_bytes - file_off;
             if (have + want > s.cap - 8) want = s.cap - 8 - have;
-            if (want) parallel_pread(fd, s.buf + have, want, (off_t)file_off, reader_threads, failed);
+            NlScan sc = read_and_scan(workers, fd, s.buf, have, want, (off_t)file_off, failed);
             file_off += want;
             have += want;
             eof = file_off >= file_bytes;
-            if (eof && have && s.buf[have - 1] != '\n') s.buf[have++] = '\n';
-            NlScan sc = scan_newlines(s.buf, have, reader_threads);
+            if (eof && have && s.buf[have - 1] != '\n') { /* a last line without its newline */
+                s.buf[have++] = '\n';
+                sc.prev = sc.last, sc.last = (int64_t)have - 1, sc.count++;
+            }
             if (eof && (sc.count & 1)) { /* a read line without its reference line: an empty reference */
                 s.buf[have++] = '\n';
                 sc.prev = sc.last, sc.last = (int64_t)have - 1, sc.count++;
@@ -2263,65 +2356,61 @@ int asm_stream_seq_file(asm_handle* h, const char* path, const asm_params* p, in
         chunk_batch[q] = nullptr;
         chunk_pairs[q] = 0;
     };
+    /* The loop runs two stages per iteration, one chunk apart: SHIP chunk c (host buffer -> HBM on the copy stream) and only then
+     * PROCESS chunk c-1 (parse, pack, aligners, results back).  Processing blocks this thread twice (the parser's totals and the
+     * packed batch), so with the stages the other way round the transfer of the next chunk could not start before the current
+     * one was packed, and the copy engine idled through every parse (round 2: 1.1e8 pairs/s; the same code in this order:
+     * DESIGN.md section 4b). */
     bool last = false;
     int64_t chunks = 0;
     size_t bytes_total = 0;
-    for (int c = 0; !last && !rc; c++) {
-        SeqSlot& s = slot[c % 3];
-        {
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return s.ready || failed.load(); });
-        }
-        if (failed) {
-            rc = fail(h, ASM_EINVAL, "asm_stream_seq_file: read failed (or one pair is longer than a chunk)");
-            break;
-        }
-        const int q = c & 1;
-        harvest(q); /* chunk c-2 used the same device buffer and staging */
-        last = s.last;
-        const int64_t n = s.pairs;
-        if (n > 0) {
-            if (n > pen_cap) { /* staging sized by the largest chunk so far (chunks hold about the same number of pairs); pen_cap = 0
-                                  until the first chunk — not "is the NW buffer there", which a mask without NW never satisfies */
-                harvest(q ^ 1);
-                const int64_t cap = n + n / 8 + 1024;
-                for (int qq = 0; qq < 2 && !rc; qq++)
-                    for (int a = 0; a < 3 && !rc; a++) {
-                        if (!((aligner_mask >> a) & 1)) continue;
-                        pool_free(h, d_pen[qq][a]);
-                        d_pen[qq][a] = nullptr;
-                        if (!h->pin_pen[qq][a] || h->pin_pen_cap[qq][a] < cap) {
-                            if (h->pin_pen[qq][a]) (void)hipHostFree(h->pin_pen[qq][a]);
-                            h->pin_pen[qq][a] = nullptr, h->pin_pen_cap[qq][a] = 0;
-                            STREAM_TRY(hipHostMalloc((void**)&h->pin_pen[qq][a], sizeof(int32_t) * (size_t)cap, hipHostMallocDefault));
-                            if (!rc) h->pin_pen_cap[qq][a] = cap;
-                        }
-                        h_pen[qq][a] = h->pin_pen[qq][a];
-                        STREAM_TRY(pool_alloc(h, (void**)&d_pen[qq][a], sizeof(int32_t) * (size_t)cap));
+    int64_t pend_pairs[2] = {0, 0};
+    size_t pend_bytes[2] = {0, 0};
+    bool pend_valid[2] = {false, false};
+    auto process = [&](int q) { /* the chunk whose text sits in d_raw[q] */
+        if (!pend_valid[q]) return;
+        pend_valid[q] = false;
+        const int64_t n = pend_pairs[q];
+        const size_t shipped = pend_bytes[q];
+        if (n <= 0 || rc) return;
+        harvest(q); /* the chunk two back used the same result staging */
+        if (n > pen_cap) { /* staging sized by the largest chunk so far (chunks hold about the same number of pairs); pen_cap = 0
+                              until the first chunk — not "is the NW buffer there", which a mask without NW never satisfies */
+            harvest(q ^ 1);
+            const int64_t cap = n + n / 8 + 1024;
+            for (int qq = 0; qq < 2 && !rc; qq++)
+                for (int a = 0; a < 3 && !rc; a++) {
+                    if (!((aligner_mask >> a) & 1)) continue;
+                    pool_free(h, d_pen[qq][a]);
+                    d_pen[qq][a] = nullptr;
+                    if (!h->pin_pen[qq][a] || h->pin_pen_cap[qq][a] < cap) {
+                        if (h->pin_pen[qq][a]) (void)hipHostFree(h->pin_pen[qq][a]);
+                        h->pin_pen[qq][a] = nullptr, h->pin_pen_cap[qq][a] = 0;
+                        STREAM_TRY(hipHostMalloc((void**)&h->pin_pen[qq][a], sizeof(int32_t) * (size_t)cap, hipHostMallocDefault));
+                        if (!rc) h->pin_pen_cap[qq][a] = cap;
                     }
-                for (int qq = 0; qq < 2 && !rc && answers; qq++) {
-                    pool_free(h, d_ans[qq]);
-                    d_ans[qq] = nullptr;
-                    STREAM_TRY(pool_alloc(h, (void**)&d_ans[qq], sizeof(int32_t) * (size_t)cap));
+                    h_pen[qq][a] = h->pin_pen[qq][a];
+                    STREAM_TRY(pool_alloc(h, (void**)&d_pen[qq][a], sizeof(int32_t) * (size_t)cap));
                 }
-                pen_cap = cap;
+            for (int qq = 0; qq < 2 && !rc && answers; qq++) {
+                pool_free(h, d_ans[qq]);
+                d_ans[qq] = nullptr;
+                STREAM_TRY(pool_alloc(h, (void**)&d_ans[qq], sizeof(int32_t) * (size_t)cap));
             }
-            STREAM_TRY(hipMemcpyAsync(d_raw[q], s.buf, s.bytes, hipMemcpyHostToDevice, copy_stream));
-            STREAM_TRY(hipEventRecord(s.ev_shipped, copy_stream));
-            s.in_flight = true;
-            STREAM_TRY(hipEventRecord(ev_h2d[q], copy_stream));
-            STREAM_TRY(hipStreamWaitEvent(h->stream, ev_h2d[q], 0));
+            pen_cap = cap;
         }
-        const size_t shipped = s.bytes;
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            s.ready = false; /* the reader may refill it once ev_shipped has fired */
-        }
-        cv.notify_all();
-        if (n <= 0 || rc) continue;
+        if (rc) return;
+        STREAM_TRY(hipStreamWaitEvent(h->stream, ev_h2d[q], 0));
         asm_batch* b = nullptr;
-        rc = batch_from_device_text(h, d_raw[q], shipped, n, ASM_GREEDY_CLEAN, &b);
-        if (rc) break;
+        const auto tp0 = std::chrono::steady_clock::now();
+        if (getenv("ASM_STREAM_DEBUG")) (void)hipEventSynchronize(ev_h2d[q]);
+        const auto tp1 = std::chrono::steady_clock::now();
+        if (!rc) rc = batch_from_device_text(h, d_raw[q], shipped, n, ASM_GREEDY_CLEAN, &b);
+        const auto tp2 = std::chrono::steady_clock::now();
+        if (getenv("ASM_STREAM_DEBUG"))
+            fprintf(stderr, "chunk %ld pairs: wait h2d %.3f ms, parse+pack %.3f ms\n", (long)n,
+                    std::chrono::duration<double, std::milli>(tp1 - tp0).count(), std::chrono::duration<double, std::milli>(tp2 - tp1).count());
+        if (rc) return;
         if (greedy_mode == ASM_GREEDY_SEQUENTIAL && do_greedy) { /* the chain of hurdle_matrix.h:136-137 across chunk boundaries */
             uint8_t summary[256];
             rc = batch_resolve_tails(h, b, nullptr, summary, false);
@@ -2347,10 +2436,44 @@ int asm_stream_seq_file(asm_handle* h, const char* path, const asm_params* p, in
         for (int a = 0; a < 3 && !rc; a++)
             if (d_pen[q][a]) STREAM_TRY(hipMemcpyAsync(h_pen[q][a], d_pen[q][a], sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
         STREAM_TRY(hipEventRecord(ev_done[q], h->stream));
+        if (rc) {
+            if (b) batch_release(b);
+            return;
+        }
         chunk_batch[q] = b, chunk_first[q] = done_pairs, chunk_pairs[q] = n;
         maxlen = b->maxlen > maxlen ? b->maxlen : maxlen;
         done_pairs += n, bytes_total += shipped, chunks++;
+    };
+    for (int c = 0; !last && !rc; c++) {
+        SeqSlot& s = slot[c % 3];
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return s.ready || failed.load(); });
+        }
+        if (failed) {
+            rc = fail(h, ASM_EINVAL, "asm_stream_seq_file: read failed (or one pair is longer than a chunk)");
+            break;
+        }
+        const int q = c & 1;
+        /* SHIP chunk c.  d_raw[q] held chunk c-2, which was processed (and its text gathered into the batch's own arrays, with
+         * this thread waiting for that) in the iteration before this one. */
+        last = s.last;
+        if (s.pairs > 0) {
+            STREAM_TRY(hipMemcpyAsync(d_raw[q], s.buf, s.bytes, hipMemcpyHostToDevice, copy_stream));
+            STREAM_TRY(hipEventRecord(s.ev_shipped, copy_stream));
+            s.in_flight = true;
+            STREAM_TRY(hipEventRecord(ev_h2d[q], copy_stream));
+        }
+        pend_pairs[q] = s.pairs, pend_bytes[q] = s.bytes, pend_valid[q] = true;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            s.ready = false; /* the reader may refill it once ev_shipped has fired */
+        }
+        cv.notify_all();
+        /* PROCESS chunk c-1 while chunk c is on its way */
+        process(q ^ 1);
     }
+    if (!rc && !failed) process(0), process(1); /* the last chunk shipped (only one of the two is pending) */
     harvest(0), harvest(1);
     if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(h, ASM_ENODEVICE, "asm_stream_seq_file: stream synchronize failed");
     if (!rc && hipMemcpy(stats->counters, d_cnt, 32, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(h, ASM_ENODEVICE, "asm_stream_seq_file: counters copy failed");
