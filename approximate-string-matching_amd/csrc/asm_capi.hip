@@ -25,6 +25,7 @@
 #include "../../include/asm_mi355x.h"
 #include "asm_kernels.h"
 #include "asm_greedy3_kernel.h"
+#include "asm_greedy_prune_kernel.h"
 #include "asm_wide.h"
 #include "asm_wave.h"
 #include "asm_group.h"
@@ -48,6 +49,11 @@ struct asm_handle {
     bool persist = true;                  /* Greedy: lane-refilling persistent kernel (ASM_PERSIST=0 disables) */
     bool persist_leap = false;            /* LEAP: the plain one-pair-per-thread kernel is faster at 1e6 pairs (ASM_PERSIST_LEAP=1) */
     int refill_greedy = 8, refill_leap = 16; /* lanes that must be idle before a wave refills (tunable by env) */
+    int greedy_prune = 0;                 /* Greedy, unit penalties, GLOBAL: band half-widths from this one up to 31 run the exactly-pruned
+                                             thread-per-pair kernel (asm_greedy_prune.h).  OFF by default (0): bit-identical, but measured
+                                             2.8x SLOWER than the wave-per-pair kernel at C3 — a wave pays for its unluckiest thread
+                                             (DESIGN.md section 7).  ASM_GREEDY_PRUNE=<k> switches it on from k up */
+    int prune_waves = 8;                  /* its waves per CU (ASM_PRUNE_WAVES: 4, 8, 12, 16; LDS holds 160 B per thread) */
     int g3_prio = 0;                      /* ASM_GREEDY_PRIO (experiment: s_setprio turns; no effect measured) */
     int g3_waves = 2;                     /* resident waves per SIMD of the fast Greedy kernel (ASM_GREEDY_WAVES = 1, 2, 3) */
     int persist_waves = 0;                /* cap on the resident waves per SIMD of the persistent kernels (ASM_PERSIST_WAVES; 0 = what fits) */
@@ -304,6 +310,72 @@ static hipError_t launch_greedy_fast(asm_handle* h, const asm_bucket& b, const G
     if (h->g3_waves == 1) return launch_greedy_fast_nt<K, 256>(h, b, ga, out, cig);
     if (h->g3_waves == 3) return launch_greedy_fast_nt<K, 768>(h, b, ga, out, cig);
     return launch_greedy_fast_nt<K, 512>(h, b, ga, out, cig);
+}
+
+/* Wide band, unit penalties, GLOBAL: set-up (wave per pair: per-lane constants), the pruned thread-per-pair kernel, and the
+ * wave-per-pair kernel over the pairs that outran the pruned kernel's pass history (asm_greedy_prune.h). */
+static int launch_greedy_pruned(asm_handle* h, const asm_bucket& b, int k, const GreedyArgs& ga, OutMap out, CigarSink cig) {
+    signed char* d_info = nullptr; /* zl of every band lane: 64 bytes per pair */
+    PrPairInfo* d_zl = nullptr;    /* the set-up kernel's per-pair summaries */
+    uint32_t* d_todo = nullptr; /* [0] = count, [1..] = pair slots */
+    int rc = ASM_OK;
+    do {
+#define TRY(call)                                                        \
+    if ((call) != hipSuccess) {                                          \
+        rc = fail(h, ASM_ENODEVICE, std::string(#call) + " failed");     \
+        break;                                                           \
+    }
+        TRY(pool_alloc(h, (void**)&d_info, 64 * (size_t)b.n + 16));
+        TRY(pool_alloc(h, (void**)&d_zl, sizeof(PrPairInfo) * (size_t)b.n));
+        TRY(pool_alloc(h, (void**)&d_todo, sizeof(uint32_t) * ((size_t)b.n + 1)));
+        TRY(hipMemsetAsync(d_todo, 0, sizeof(uint32_t), h->stream));
+        {
+            int64_t blocks = (int64_t)h->num_cus * 8; /* wave per pair, striding */
+            const int64_t need = (b.n + 3) / 4;
+            if (blocks > need) blocks = need;
+            hipLaunchKernelGGL(prune_setup_kernel, dim3((unsigned)blocks), dim3(ASM_BLOCK), 0, h->stream, (const uint4*)b.planes,
+                               (const uint32_t*)b.lens, (long)b.n, b.w4, k, d_info, d_zl);
+            TRY(hipGetLastError());
+        }
+        {
+            auto kern_args_k = k;
+            (void)kern_args_k;
+            hipError_t e;
+            const G3Sig sig = {ga.sig_match, ga.sig_mismatch, ga.sig_indel};
+#define PRUNE_LAUNCH(NT)                                                                                                      \
+    {                                                                                                                         \
+        auto kern = greedy_prune_kernel<NT>;                                                                                  \
+        const size_t lds = pr_lds_bytes(NT);                                                                                  \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+        if (e == hipSuccess) {                                                                                                \
+            int64_t blocks = h->num_cus;                                                                                      \
+            const int64_t need = (b.n + NT - 1) / NT;                                                                         \
+            if (blocks > need) blocks = need;                                                                                 \
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NT), lds, h->stream, (const uint4*)b.planes,                \
+                               (const uint32_t*)b.lens, (long)b.n, b.w4, k, sig, (const signed char*)d_info,                  \
+                               (const PrPairInfo*)d_zl, out, cig, h->refill_greedy, d_todo + 1, d_todo);                      \
+            e = hipGetLastError();                                                                                            \
+        }                                                                                                                     \
+    }
+            switch (h->prune_waves) {
+                case 4: PRUNE_LAUNCH(256) break;
+                case 12: PRUNE_LAUNCH(768) break;
+                case 16: PRUNE_LAUNCH(1024) break;
+                default: PRUNE_LAUNCH(512) break;
+            }
+#undef PRUNE_LAUNCH
+            TRY(e);
+        }
+        /* the pairs the pruned kernel handed back (more passes than its history holds): a fixed small grid walks the list */
+        TRY(hipMemsetAsync(h->d_pair_queue, 0, sizeof(unsigned long long), h->stream));
+        hipLaunchKernelGGL(greedy_wave_kernel<true>, dim3((unsigned)h->num_cus), dim3(ASM_BLOCK), 0, h->stream, (const uint4*)b.planes,
+                           (const uint32_t*)b.lens, (long)b.n, b.w4, k, ga, out, cig, h->d_pair_queue, (const uint32_t*)(d_todo + 1),
+                           (const uint32_t*)d_todo);
+        TRY(hipGetLastError());
+#undef TRY
+    } while (0);
+    pool_free(h, d_info), pool_free(h, d_zl), pool_free(h, d_todo); /* recycled in stream order */
+    return rc;
 }
 
 template <int K>
@@ -615,6 +687,8 @@ int asm_create(asm_handle** out, int device) {
     if ((env = getenv("ASM_GREEDY_FAST"))) h->greedy_fast = env[0] != '0';
     if ((env = getenv("ASM_PERSIST_WAVES"))) h->persist_waves = atoi(env);
     if ((env = getenv("ASM_GREEDY_PRIO"))) h->g3_prio = atoi(env);
+    if ((env = getenv("ASM_GREEDY_PRUNE"))) h->greedy_prune = atoi(env);
+    if ((env = getenv("ASM_PRUNE_WAVES"))) h->prune_waves = atoi(env);
     if ((env = getenv("ASM_GREEDY_WAVES"))) h->g3_waves = atoi(env);
     if ((env = getenv("ASM_REFILL_LEAP"))) h->refill_leap = atoi(env);
     {
@@ -1307,14 +1381,19 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
                     /* 65..79 band lanes: sixteen threads per pair, five lanes each (asm_group.h): 1.78 ms per 10^6 C2 pairs
                      * against 2.25 ms for the two-wavefront kernel */
                     HIPCHK(h, launch_greedy_group(h->stream, planes, lens, b.n, b.w4, (int)p->k, ga, out, cig, h->num_cus));
+                } else if (p->k <= PR_MAXK && h->greedy_prune > 0 && p->k >= h->greedy_prune && h->wave_kernels && unit && !ga.semi &&
+                           ga.sig_mismatch <= 0.0 && ga.sig_indel <= 0.0 && ga.sig_match >= 0.0) {
+                    /* a pass looks at the few lanes that can matter (exact pruning, asm_greedy_prune.h) */
+                    const int prc = launch_greedy_pruned(h, b, (int)p->k, ga, out, cig);
+                    if (prc != ASM_OK) return prc;
                 } else if (p->k <= ASM_WAVE_MAX_K && h->wave_kernels && unit && !ga.semi) {
                     HIPCHK(h, hipMemsetAsync(h->d_pair_queue, 0, sizeof(unsigned long long), h->stream));
                     launch_wave_per_pair(h->stream, greedy_wave_kernel<true>, b.n, h->num_cus, planes, lens, (long)b.n, b.w4,
-                                         (int)p->k, ga, out, cig, h->d_pair_queue);
+                                         (int)p->k, ga, out, cig, h->d_pair_queue, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
                 } else if (p->k <= ASM_WAVE_MAX_K && h->wave_kernels && (long)p->o + 62L * p->e < 16000L) {
                     HIPCHK(h, hipMemsetAsync(h->d_pair_queue, 0, sizeof(unsigned long long), h->stream));
                     launch_wave_per_pair(h->stream, greedy_wave_kernel<false>, b.n, h->num_cus, planes, lens, (long)b.n, b.w4,
-                                         (int)p->k, ga, out, cig, h->d_pair_queue);
+                                         (int)p->k, ga, out, cig, h->d_pair_queue, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
                 } else if (h->wave_kernels && (long)p->o + 100L * p->e < 16000L)
                     launch_greedy_wave2(h->stream, planes, lens, b.n, b.w4, (int)p->k, ga, out, cig, h->num_cus);
                 else

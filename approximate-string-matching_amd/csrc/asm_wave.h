@@ -781,15 +781,19 @@ template <bool UNIT> /* UNIT: x = o = e = 1 at compile time */
 __global__ __launch_bounds__(ASM_BLOCK) void greedy_wave_kernel(const uint4* __restrict__ planes,
                                                                 const uint32_t* __restrict__ lens, long n, int w4,
                                                                 int k, GreedyArgs args, OutMap out, CigarSink cig,
-                                                                unsigned long long* __restrict__ queue) {
+                                                                unsigned long long* __restrict__ queue,
+                                                                const uint32_t* __restrict__ list /* or null: pairs 0..n-1 */,
+                                                                const uint32_t* __restrict__ list_count) {
     const int t = threadIdx.x & 63;
     const int nl = 2 * k + 1;
     const bool active = t < nl;
     const int lane = t - k;
     const int x = UNIT ? 1 : args.x, o = UNIT ? 1 : args.o, e = UNIT ? 1 : args.e;
     const bool semi = UNIT ? false : args.semi != 0;
+    const long n_work = list ? (long)*list_count : n; /* a list of pair slots (what the pruned kernel handed back), or all of them */
     PairQueue pq;
-    for (long i = pq.first(queue, n); i < n; i = pq.next(queue, i, n)) {
+    for (long iq = pq.first(queue, n_work); iq < n_work; iq = pq.next(queue, iq, n_work)) {
+        const long i = list ? (long)list[iq] : iq;
         const V128 A0 = v_from_uint4(planes[((long)0 * w4) * n + i]);
         const V128 A1 = v_from_uint4(planes[((long)1 * w4) * n + i]);
         const V128 B0 = v_from_uint4(planes[((long)2 * w4) * n + i]);
