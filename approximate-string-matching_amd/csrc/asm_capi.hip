@@ -309,6 +309,8 @@ static hipError_t launch_greedy_fast(asm_handle* h, const asm_bucket& b, const G
      * alone (118 us against 130) and beside NW -> LEAP in asm_run_benchmark_async */
     if (h->g3_waves == 1) return launch_greedy_fast_nt<K, 256>(h, b, ga, out, cig);
     if (h->g3_waves == 3) return launch_greedy_fast_nt<K, 768>(h, b, ga, out, cig);
+    if (h->g3_waves == 15) return launch_greedy_fast_nt<K, 384>(h, b, ga, out, cig); /* 1.5: six waves per CU */
+    if (h->g3_waves == 25) return launch_greedy_fast_nt<K, 640>(h, b, ga, out, cig); /* 2.5: ten waves per CU */
     return launch_greedy_fast_nt<K, 512>(h, b, ga, out, cig);
 }
 

@@ -31,11 +31,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md §Chip-level parameters)
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")  # workload C2; other workloads: r02_pmc_<workload>.json
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")  # workload C2; other workloads: r03_pmc_<workload>.json
 
 
 def pmc_path(workload):
-    return PMC_FILE if workload == "C2" else os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % workload.lower())
+    return PMC_FILE if workload == "C2" else os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % workload.lower())
 # repack mode of the timed step: 1 = strictly in order (default), 2 = pipelined (the pack of step s+1 runs beside the aligners of
 # step s on its own stream; ASM_PACK_PIPELINE=1).  Measured at C2: 0.280 ms/step pipelined against 0.263 in order — pack's
 # workgroups take CUs away from the persistent Greedy kernel, whose waves own static slices of the batch (0.151 -> 0.222 ms).

@@ -3,9 +3,9 @@
 set -e
 cd "$(dirname "$0")/.."
 F=gpurun_out/final
-cp $F/r02_pmc.json profiles/r02_pmc.json
-cp $F/valu_rates.txt profiles/r02_valu_rates.txt
-cp $F/bench.json profiles/r02_bench_c2.json
+cp $F/r03_pmc.json profiles/r03_pmc.json
+cp $F/valu_rates.txt profiles/r03_valu_rates.txt
+cp $F/bench.json profiles/r03_bench_c2.json
 S=$(ls $F/stats/*/*kernel_stats.csv $F/stats/*kernel_stats.csv 2>/dev/null | head -1)
-[ -n "$S" ] && cp "$S" profiles/r02_kernel_stats_c2.csv
-ls -la profiles/r02_*
+[ -n "$S" ] && cp "$S" profiles/r03_kernel_stats_c2.csv
+ls -la profiles/r03_*
