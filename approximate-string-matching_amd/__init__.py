@@ -156,6 +156,7 @@ def load_library() -> ctypes.CDLL:
         "asm_simd_ed_batch_async": (i32, [vp, vp, i32, i32, i32, vp, vp]),
         "asm_simd_ed_affine_batch_async": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
         "asm_shd_filter_batch_async": (i32, [vp, vp, i32, vp]),
+        "asm_pipeline_join_async": (i32, [vp]),
         "asm_profile_enable": (i32, [vp, i32, c.c_uint32]),
         "asm_profile_read": (i32, [vp, vp, i32, vp]),
         "asm_count_equal_async": (i32, [vp, vp, vp, i64, vp]),
@@ -582,9 +583,14 @@ class Engine:
                             d_greedy: Optional[int], d_counters: Optional[int], repack: bool = True,
                             d_answers: Optional[int] = None) -> None:
         """`_run_benchmark` over the whole resident batch (pack, NW, LEAP, Greedy, counters) in one call.  repack: False / True
-        (pack in stream order) / 2 (pipelined: this call's pack overlaps the previous call's aligners)."""
+        (pack in stream order) / 2 (pipelined: this call's pack overlaps the previous call's aligners) / 3 (overlapped calls:
+        alternate two sets of output arrays from call to call and end with pipeline_join_async)."""
         self._chk(self.lib.asm_run_benchmark_async(self.h, batch.ptr, ctypes.byref(params), int(repack), d_nw,
                                                    d_leap, d_greedy, d_answers, d_counters))
+
+    def pipeline_join_async(self) -> None:
+        """Orders everything the overlapped calls (repack=3) enqueued before what comes next on the handle's stream."""
+        self._chk(self.lib.asm_pipeline_join_async(self.h))
 
     # ---- timing ----
     def profile_enable(self, max_calls: int, kernel_mask: int = 0xF) -> None:

@@ -42,6 +42,15 @@ struct asm_handle {
     hipStream_t side_stream = nullptr;    /* asm_run_benchmark_async runs Greedy beside the NW -> LEAP chain */
     hipStream_t pack_stream = nullptr;    /* ... and, with repack = 2, packs for this call while the previous call still aligns */
     hipEvent_t ev_packed = nullptr;
+    hipStream_t acc_stream = nullptr;     /* repack = 3: the counters of a call, behind both of its chains */
+    hipEvent_t ev_leap = nullptr, ev_tail = nullptr;
+    bool tail_set = false;
+    hipEvent_t ev_out[2] = {nullptr, nullptr}; /* repack = 3: the counters of the call before last (same output arrays) are done */
+    unsigned calls3 = 0;
+    bool pipe_prev = false;               /* the previous asm_run_benchmark_async call was a pipelined one (repack 2 or 3) */
+    hipEvent_t ev_gate = nullptr;         /* repack = 2: the next call's pack starts behind this point of the current call */
+    bool gate_set = false;
+    int pack_gate = -1;                   /* 0 none, 1 behind NW, 2 behind LEAP; -1 = 1 with repack 2, 0 with repack 3 (ASM_PACK_GATE) */
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap = true;                  /* ASM_OVERLAP=0: everything on one stream */
     std::string err;
@@ -660,8 +669,22 @@ int asm_create(asm_handle** out, int device) {
     h->stream = h->own_stream;
     HIPCHK(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
     HIPCHK(h, hipMalloc((void**)&h->d_pair_queue, sizeof(unsigned long long)));
-    HIPCHK(h, hipStreamCreateWithFlags(&h->pack_stream, hipStreamNonBlocking));
+    {
+        const char* pp = getenv("ASM_PACK_PRIO");
+        int lo = 0, hi = 0;
+        if (pp && atoi(pp) != 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess)
+            HIPCHK(h, hipStreamCreateWithPriority(&h->pack_stream, hipStreamNonBlocking, atoi(pp) > 0 ? lo : hi));
+        else
+            HIPCHK(h, hipStreamCreateWithFlags(&h->pack_stream, hipStreamNonBlocking));
+        const char* pg = getenv("ASM_PACK_GATE");
+        if (pg) h->pack_gate = atoi(pg);
+    }
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_packed, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_gate, hipEventDisableTiming));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->acc_stream, hipStreamNonBlocking));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_leap, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_tail, hipEventDisableTiming));
+    for (hipEvent_t& ev : h->ev_out) HIPCHK(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     hipDeviceProp_t prop;
@@ -718,6 +741,12 @@ int asm_destroy(asm_handle* h) {
     if (h->d_sort) (void)hipFree(h->d_sort);
     if (h->pack_stream) (void)hipStreamDestroy(h->pack_stream);
     if (h->ev_packed) (void)hipEventDestroy(h->ev_packed);
+    if (h->ev_gate) (void)hipEventDestroy(h->ev_gate);
+    if (h->ev_leap) (void)hipEventDestroy(h->ev_leap);
+    if (h->ev_tail) (void)hipEventDestroy(h->ev_tail);
+    for (hipEvent_t ev : h->ev_out)
+        if (ev) (void)hipEventDestroy(ev);
+    if (h->acc_stream) (void)hipStreamDestroy(h->acc_stream);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->d_todo) (void)hipFree(h->d_todo);
@@ -767,6 +796,15 @@ int asm_synchronize(asm_handle* h) {
     if (!h) return fail(nullptr, ASM_EINVAL, "asm_synchronize: NULL handle");
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->tail_set) HIPCHK(h, hipStreamSynchronize(h->acc_stream)); /* calls with repack = 3 end on the library's own streams */
+    return ASM_OK;
+}
+
+int asm_pipeline_join_async(asm_handle* h) {
+    if (!h) return fail(nullptr, ASM_EINVAL, "asm_pipeline_join_async: NULL handle");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->tail_set) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_tail, 0));
+    h->pipe_prev = false; /* the next pipelined call starts behind this point of the caller's stream: any output set may follow */
     return ASM_OK;
 }
 
@@ -1856,6 +1894,7 @@ int asm_profile_read(asm_handle* h, float* ms, int cap_calls, int* n_calls) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->side_stream) HIPCHK(h, hipStreamSynchronize(h->side_stream));
     if (h->pack_stream) HIPCHK(h, hipStreamSynchronize(h->pack_stream));
+    if (h->acc_stream) HIPCHK(h, hipStreamSynchronize(h->acc_stream));
     const int n = (int)h->prof_mask.size();
     *n_calls = n;
     for (int c = 0; c < n && c < cap_calls; c++)
@@ -1883,8 +1922,13 @@ int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, in
         pmask |= 1u << (q);                                                  \
     }
     hipStream_t main_stream = h->stream;
+    if (repack != 3 && h->tail_set) { /* earlier overlapped calls: everything of theirs before anything of this one */
+        HIPCHK(h, hipSetDevice(h->device));
+        HIPCHK(h, hipStreamWaitEvent(main_stream, h->ev_tail, 0));
+        h->tail_set = false;
+    }
     bool pipelined = false;
-    if (repack == 2 && b->n > 0) {
+    if ((repack == 2 || repack == 3) && b->n > 0) {
         /* Pipelined repack: pack fills the OTHER set of planes on its own stream, so it runs beside the aligners of the previous
          * call (which read the current set) instead of behind them; this call's aligners wait for it.  The set it fills was last
          * read two calls ago (ev_consumed).  The caller guarantees that nothing enqueued since the previous call changes what
@@ -1906,6 +1950,16 @@ int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, in
             b->bk[q].lens = b->d_lens + b->pb.start[q];
         }
         HIPCHK(h, hipStreamWaitEvent(h->pack_stream, b->ev_consumed[nxt], 0));
+        if (!h->pipe_prev) { /* first of a run of pipelined calls: behind whatever the caller's stream holds so far */
+            HIPCHK(h, hipEventRecord(h->ev_fork, main_stream));
+            HIPCHK(h, hipStreamWaitEvent(h->pack_stream, h->ev_fork, 0));
+        }
+        /* ... and not before the previous call's persistent Greedy kernel is resident everywhere: pack's thousands of short
+         * workgroups, dispatched at the same moment, keep Greedy's 122 KB-LDS workgroups off the CUs (0.280 ms/step); behind
+         * the previous NW they find Greedy running and take the slots NW left (0.238).  With overlapped calls (repack = 3) the
+         * pack chain runs a call ahead and meets no Greedy launch: no gate there (0.229 against 0.251 gated) */
+        const int gate = h->pack_gate >= 0 ? h->pack_gate : (repack == 2 ? 1 : 0);
+        if (h->gate_set && gate) HIPCHK(h, hipStreamWaitEvent(h->pack_stream, h->ev_gate, 0));
         PROF(0, 0, h->pack_stream)
         h->stream = h->pack_stream;
         rc = asm_batch_pack_async(h, b);
@@ -1932,6 +1986,69 @@ int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, in
         rc = asm_align_batch_async(h, b, ASM_GREEDY, p, d_greedy);
         PROF(3, 1, main_stream)
     }
+    if (repack == 3 && pipelined && !greedy_first && !rc) {
+        /* OVERLAPPED calls: nothing of this call waits for the previous call's Greedy, and the caller's stream is not joined
+         * here (asm_pipeline_join_async does that).  Three chains run through consecutive calls — NW -> LEAP -> NW -> ... on the
+         * caller's stream, Greedy -> Greedy on the side stream, pack -> pack on the pack stream — and each call's counters
+         * run behind its two aligner chains on a fourth stream, whose event also frees the call's plane set for the pack two
+         * calls later (and, with the caller alternating output arrays, says those arrays may be written again). */
+        /* the output arrays were last written two calls ago (the caller alternates): behind that call's counters.  For calls
+         * on ONE batch ev_packed already implies it; calls on different batches have nothing else that orders them. */
+        hipEvent_t out_free = h->ev_out[h->calls3 & 1u];
+        if (h->calls3 >= 2) {
+            HIPCHK(h, hipStreamWaitEvent(main_stream, out_free, 0));
+            if (d_greedy) HIPCHK(h, hipStreamWaitEvent(h->side_stream, out_free, 0));
+        }
+        if (d_greedy) {
+            /* one side stream: Greedy kernels of consecutive calls in a row.  Alternating two streams, so that the next call's
+             * workgroups move in as the previous call's leave, was measured at 0.273 ms/step against 0.233 — two persistent
+             * kernels that each want a CU's LDS keep each other out */
+            hipStream_t side = h->side_stream;
+            HIPCHK(h, hipStreamWaitEvent(side, h->ev_packed, 0));
+            PROF(3, 0, side)
+            h->stream = side;
+            rc = asm_align_batch_async(h, b, ASM_GREEDY, p, d_greedy);
+            h->stream = main_stream;
+            PROF(3, 1, side)
+            if (!rc) HIPCHK(h, hipEventRecord(h->ev_join, side));
+        }
+        if (!rc && d_nw) {
+            PROF(1, 0, main_stream)
+            rc = asm_align_batch_async(h, b, ASM_NW, p, d_nw);
+            PROF(1, 1, main_stream)
+            if (!rc && h->pack_gate == 1) {
+                HIPCHK(h, hipEventRecord(h->ev_gate, main_stream));
+                h->gate_set = true;
+            }
+        }
+        if (!rc && d_leap) {
+            PROF(2, 0, main_stream)
+            rc = asm_align_batch_hinted_async(h, b, ASM_LEAP, p, d_nw, d_leap);
+            PROF(2, 1, main_stream)
+            if (!rc && h->pack_gate == 2) { /* (explicit ASM_PACK_GATE only) */
+                HIPCHK(h, hipEventRecord(h->ev_gate, main_stream));
+                h->gate_set = true;
+            }
+        }
+        if (pe) h->prof_mask.push_back(pmask);
+        if (rc) return rc;
+        HIPCHK(h, hipEventRecord(h->ev_leap, main_stream));
+        HIPCHK(h, hipStreamWaitEvent(h->acc_stream, h->ev_leap, 0));
+        if (d_greedy) HIPCHK(h, hipStreamWaitEvent(h->acc_stream, h->ev_join, 0));
+        if (d_counters && d_nw) {
+            h->stream = h->acc_stream;
+            rc = asm_accuracy_async(h, d_nw, d_leap, d_greedy, d_answers, b->n, d_counters);
+            h->stream = main_stream;
+            if (rc) return rc;
+        }
+        HIPCHK(h, hipEventRecord(b->ev_consumed[b->cur], h->acc_stream));
+        HIPCHK(h, hipEventRecord(out_free, h->acc_stream));
+        h->calls3++;
+        HIPCHK(h, hipEventRecord(h->ev_tail, h->acc_stream));
+        h->tail_set = true;
+        h->pipe_prev = true;
+        return ASM_OK;
+    }
     const bool fork = h->overlap && d_greedy && (d_nw || d_leap) && !rc && !greedy_first;
     if (fork) {
         HIPCHK(h, hipEventRecord(h->ev_fork, main_stream));
@@ -1947,12 +2064,20 @@ int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, in
         PROF(1, 0, main_stream)
         rc = asm_align_batch_async(h, b, ASM_NW, p, d_nw);
         PROF(1, 1, main_stream)
+        if (!rc && (h->pack_gate == 1 || (h->pack_gate < 0 && repack == 2))) {
+            HIPCHK(h, hipEventRecord(h->ev_gate, main_stream));
+            h->gate_set = true;
+        }
     }
     /* LEAP is scheduled by the NW penalties just computed (same work, sorted inside each workgroup) */
     if (!rc && d_leap) {
         PROF(2, 0, main_stream)
         rc = asm_align_batch_hinted_async(h, b, ASM_LEAP, p, greedy_first ? d_greedy : d_nw, d_leap);
         PROF(2, 1, main_stream)
+        if (!rc && h->pack_gate == 2) {
+            HIPCHK(h, hipEventRecord(h->ev_gate, main_stream));
+            h->gate_set = true;
+        }
     }
     if (fork) {
         if (!rc) HIPCHK(h, hipStreamWaitEvent(main_stream, h->ev_join, 0));
@@ -1965,6 +2090,7 @@ int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, in
     if (pe) h->prof_mask.push_back(pmask);
     if (pipelined && !rc) HIPCHK(h, hipEventRecord(b->ev_consumed[b->cur], main_stream)); /* Greedy's stream has joined above */
     if (!rc && d_counters && d_nw) rc = asm_accuracy_async(h, d_nw, d_leap, d_greedy, d_answers, b->n, d_counters);
+    h->pipe_prev = pipelined;
     return rc;
 }
 

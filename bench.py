@@ -36,10 +36,16 @@ PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")  # workload C2; other 
 
 def pmc_path(workload):
     return PMC_FILE if workload == "C2" else os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % workload.lower())
-# repack mode of the timed step: 1 = strictly in order (default), 2 = pipelined (the pack of step s+1 runs beside the aligners of
-# step s on its own stream; ASM_PACK_PIPELINE=1).  Measured at C2: 0.280 ms/step pipelined against 0.263 in order — pack's
-# workgroups take CUs away from the persistent Greedy kernel, whose waves own static slices of the batch (0.151 -> 0.222 ms).
-PACK_MODE = 2 if os.environ.get("ASM_PACK_PIPELINE", "0") == "1" else 1
+# repack mode of the timed step (ASM_PACK_PIPELINE): "0" -> 1 = strictly in order; "1" -> 2 = pipelined pack (the pack of step
+# s+1 beside the aligners of step s, started behind that step's NW so that it does not keep the persistent Greedy kernel's
+# workgroups off the CUs); "2" -> 3 = overlapped steps (default; as 2, and no step waits for the previous step's Greedy: three
+# chains of kernels through the K steps, two sets of output arrays).  Every step still does all of its work inside the timed
+# region; C2 on one box: 0.257 / 0.238 / 0.229 ms per step.  The in-order figure is reported beside the headline.
+PACK_MODE = {"0": 1, "1": 2, "2": 3}[os.environ.get("ASM_PACK_PIPELINE", "2")]
+STEP_FORMS = {1: "in order: pack, then the aligners, then the counters, every step behind the previous one",
+              2: "pipelined pack (repack=2): the pack of step s+1 fills a second set of planes beside the aligners of step s",
+              3: "overlapped steps (repack=3): two sets of planes and of output arrays; the pack of step s+1 and the aligners of "
+                 "consecutive steps overlap, each step's counters run behind its own aligners; joined before the final barrier"}
 KERNEL_SOURCES = ("approximate-string-matching_amd/csrc", "approximate-string-matching_amd/Makefile")
 
 
@@ -271,11 +277,19 @@ def run(args, asm, eng, torch, dist, stream, rank, world, cfg, params, first, n,
     counters = torch.zeros(4, dtype=torch.int64, device="cuda")  # total, nw_ok, leap_ok, greedy_ok
     d_cnt = counters.data_ptr()
     d_nw, d_leap, d_greedy = d_pen.get(asm.NW), d_pen.get(asm.LEAP), d_pen.get(asm.GREEDY)
+    # overlapped calls (repack = 3) alternate between two sets of output arrays
+    d_alt = {a: eng.malloc(4 * n) for a in aligners} if PACK_MODE == 3 else d_pen
+    calls = [0]
 
     def step(timers=None, b=batch, repack=True):
         if timers is None:
             # `_run_benchmark` for the whole batch: pack, aligners, counters — one C-ABI call, five launches
-            eng.run_benchmark_async(b, params, d_nw, d_leap, d_greedy, d_cnt, repack=(PACK_MODE if repack else 0))
+            if PACK_MODE == 3 and repack:
+                o = d_alt if calls[0] & 1 else d_pen
+                calls[0] += 1
+                eng.run_benchmark_async(b, params, o.get(asm.NW), o.get(asm.LEAP), o.get(asm.GREEDY), d_cnt, repack=3)
+            else:
+                eng.run_benchmark_async(b, params, d_nw, d_leap, d_greedy, d_cnt, repack=(PACK_MODE if repack else 0))
             return
         seq = [("pack", lambda: eng.pack_async(b))]
         for a in aligners:
@@ -296,6 +310,7 @@ def run(args, asm, eng, torch, dist, stream, rank, world, cfg, params, first, n,
 
     for _ in range(args.warmup):
         step()
+    eng.pipeline_join_async()
     # stand-alone durations: a separately instrumented pass with the kernels one after the other on one stream (what a
     # kernel costs when it has the GPU to itself; in the timed region Greedy shares it with NW and LEAP) — run before
     # the timed region, where it also tells which kernel is the dominant one
@@ -319,6 +334,7 @@ def run(args, asm, eng, torch, dist, stream, rank, world, cfg, params, first, n,
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    eng.pipeline_join_async()  # overlapped calls end on the library's streams: order them before what follows on `stream`
     ar_wall = None
     if dist is not None:
         if coll_device.type == "cuda":
@@ -350,6 +366,18 @@ def run(args, asm, eng, torch, dist, stream, rank, world, cfg, params, first, n,
     eng.profile_enable(0, 0)
     q_dom = names.index(dom)
     region_ms = {dom: float(region[:, q_dom].mean())} if region.shape[0] and (region[:, q_dom] >= 0).all() else {dom: kernel_ms[dom]}
+
+    # the same K steps strictly in order (repack = 1), for the record: what a caller without a second batch in flight gets
+    in_order_ms = None
+    if PACK_MODE != 1:
+        scratch_cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
+        k_in = min(args.steps, 20)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(k_in):
+            eng.run_benchmark_async(batch, params, d_nw, d_leap, d_greedy, scratch_cnt.data_ptr(), repack=1)
+        barrier()
+        in_order_ms = (time.perf_counter() - t1) / k_in * 1e3
 
     sequential = None
     if not args.no_sequential and asm.GREEDY in aligners:
@@ -405,7 +433,9 @@ def run(args, asm, eng, torch, dist, stream, rank, world, cfg, params, first, n,
                         + "+".join(asm.ALIGNER_NAMES[a] for a in aligners) + ", greedy tails=clean",
             "pairs_per_gpu": n,
             "sharding": "independent pairs, contiguous shard per rank, one 32-byte all-reduce of counters",
+            "steps_run": STEP_FORMS[PACK_MODE],
         },
+        "ms_per_step_in_order": in_order_ms,
         "ms_per_step_per_rank": per_rank_ms,
         "allreduce_ms": allreduce_ms,
         "kernel_ms_in_timed_region": region_ms,
@@ -453,20 +483,25 @@ def extra_leg(args, asm, eng, torch, dist, stream, rank, world, workload, coll_d
     lo, hi = asm.shard_bounds(total, world, rank)
     n = hi - lo
     batch = eng.generate(cfg, lo, n)
-    d = [eng.malloc(4 * max(n, 1)) for _ in range(3)]
+    d = [eng.malloc(4 * max(n, 1)) for _ in range(6 if PACK_MODE == 3 else 3)]
     counters = torch.zeros(4, dtype=torch.int64, device="cuda")
     steps = args.extra_steps
+    calls = [0]
 
     def step():
-        eng.run_benchmark_async(batch, params, d[0], d[1], d[2], counters.data_ptr(), repack=1)
+        o = d[3:] if (PACK_MODE == 3 and calls[0] & 1) else d[:3]
+        calls[0] += 1
+        eng.run_benchmark_async(batch, params, o[0], o[1], o[2], counters.data_ptr(), repack=PACK_MODE)
 
     step()
+    eng.pipeline_join_async()
     barrier()
     counters.zero_()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    eng.pipeline_join_async()
     ar0 = time.perf_counter()
     if coll_device.type == "cuda":
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))

@@ -268,10 +268,21 @@ int asm_accuracy_async(asm_handle* h, const int32_t* d_nw, const int32_t* d_leap
  * repack: 0 = use the planes as they are; 1 = pack first, in stream order; 2 = pack first, PIPELINED: the pack of this call
  * fills a second set of planes on its own stream and so overlaps the aligners of the previous call (pack waits on memory for
  * half of its time, the aligners are instruction-bound); this call's aligners wait for it.  With 2 the caller guarantees that
- * nothing it enqueued since the previous call on this batch changes what pack reads. */
+ * nothing it enqueued since the previous call on this batch changes what pack reads.
+ * 3 = OVERLAPPED CALLS, the form a caller with a stream of batches (or of passes) wants: as 2, and in addition nothing of this
+ * call waits for the previous call's Greedy kernel — consecutive calls form three chains (NW -> LEAP -> NW ..., Greedy -> Greedy,
+ * pack -> pack) with each call's counters behind its own aligners on a fourth stream.  The caller's stream is NOT joined: the
+ * outputs and counters of all calls so far are complete on it after asm_pipeline_join_async (asm_synchronize also waits for
+ * them).  The caller ALTERNATES between two sets of output arrays from call to call (a set is written again two calls later,
+ * when the library has seen its counters finish), and calls asm_pipeline_join_async before it touches the batch or the outputs
+ * in any other way.  A later call with repack != 3 joins by itself. */
 int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, int repack, int32_t* d_nw,
                             int32_t* d_leap, int32_t* d_greedy, const int32_t* d_answers,
                             unsigned long long* d_counters);
+
+/* Joins the overlapped calls (repack = 3) into the handle's stream: everything they enqueued is ordered before whatever is
+ * enqueued on that stream next.  Enqueue only; a no-op when there are none. */
+int asm_pipeline_join_async(asm_handle* h);
 
 /* Per-kernel timing INSIDE a caller's timed region: after asm_profile_enable(h, max_calls, kernel_mask) the next max_calls
  * calls of asm_run_benchmark_async bracket the selected kernels (bit 0 pack, 1 NW, 2 LEAP, 3 Greedy) with HIP events

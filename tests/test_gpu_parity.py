@@ -737,6 +737,58 @@ def test_pipelined_repack_gives_the_same_results(asm, engine, oracle, wl, n):
         engine.free(x)
 
 
+@pytest.mark.parametrize("wl,n", [("C2", 30000), ("C5", 12000)])
+def test_overlapped_calls_give_the_same_results(asm, engine, oracle, wl, n):
+    """asm_run_benchmark_async with repack = 3: consecutive calls overlap (no call waits for the previous call's Greedy, the
+    counters run on their own stream), the caller alternates two sets of output arrays and joins at the end.  Two DIFFERENT
+    batches take turns, so that a kernel running in the wrong order, or counters reading arrays a later call already rewrites,
+    would show: both output sets must hold the penalties of the batch that wrote them last and the counters the exact sum."""
+    cfg, _, params = asm.workload(wl)
+    hbs = [asm.generate_pairs(cfg, 13, n), asm.generate_pairs(cfg, 977, n)]
+    batches = [engine.upload(hb, asm.GREEDY_CLEAN) for hb in hbs]
+    sets = [[engine.malloc(4 * n) for _ in range(3)] for _ in range(2)]
+    d_cnt = engine.malloc(32)
+    engine.memset_async(d_cnt, 0, 32)
+    want = []
+    for hb in hbs:
+        want.append((oracle.nw(hb), oracle.leap(hb, params.k), oracle.greedy(hb, params.k, mode=1)))
+    ok = [np.maximum(*hb.lengths()) <= 256 for hb in hbs]
+    order = [0, 1, 1, 0, 0, 0, 1, 0, 1, 1, 1, 0, 1]
+    for c, which in enumerate(order):
+        o = sets[c & 1]
+        engine.run_benchmark_async(batches[which], params, o[0], o[1], o[2], d_cnt, repack=3)
+    engine.pipeline_join_async()
+    last = {(len(order) - 1) & 1: order[-1], (len(order) - 2) & 1: order[-2]}
+    expect = np.zeros(4, np.int64)
+    got_leap = {}
+    for s_i, which in last.items():
+        nw, leap, greedy = want[which]
+        assert np.array_equal(engine.to_host(sets[s_i][0], n), nw)
+        got_leap[which] = engine.to_host(sets[s_i][1], n)
+        assert np.array_equal(got_leap[which][ok[which]], leap[ok[which]])
+        assert np.array_equal(engine.to_host(sets[s_i][2], n), greedy)
+    for which in order:
+        nw, leap, greedy = want[which]
+        gl = got_leap.get(which)
+        if gl is None:  # (both batches are among the last two calls in `order`)
+            gl = leap
+        expect += np.array([n, n, int((gl == nw).sum()), int((greedy == nw).sum())])
+    assert engine.to_host(d_cnt, 4, np.uint64).tolist() == expect.tolist()
+    # a plain call afterwards joins by itself, and the batches are still normal batches
+    engine.run_benchmark_async(batches[0], params, sets[0][0], sets[0][1], sets[0][2], d_cnt, repack=1)
+    assert np.array_equal(engine.to_host(sets[0][2], n), want[0][2])
+    assert np.array_equal(engine.align(batches[1], asm.GREEDY, params), want[1][2])
+    # ... and a new run of overlapped calls may start with either set
+    for c in range(3):
+        o = sets[(c + 1) & 1]
+        engine.run_benchmark_async(batches[1], params, o[0], o[1], o[2], d_cnt, repack=3)
+    engine.synchronize()  # waits for the overlapped calls too
+    assert np.array_equal(engine.to_host(sets[0][0], n), want[1][0])
+    assert np.array_equal(engine.to_host(sets[1][2], n), want[1][2])
+    for x in sets[0] + sets[1] + [d_cnt]:
+        engine.free(x)
+
+
 def test_profile_events_inside_run_benchmark(asm, engine):
     """asm_profile_enable / asm_profile_read: per-kernel HIP events recorded by the library inside asm_run_benchmark_async
     (what bench.py uses for the dominant kernel's duration inside its timed region)."""
