@@ -50,6 +50,7 @@ struct asm_handle {
     bool pipe_prev = false;               /* the previous asm_run_benchmark_async call was a pipelined one (repack 2 or 3) */
     hipEvent_t ev_gate = nullptr;         /* repack = 2: the next call's pack starts behind this point of the current call */
     bool gate_set = false;
+    int simd_quad_min = 1;                /* SIMD_ED affine, strings <= 128: four threads per pair from this gap threshold on (ASM_SIMD_QUAD; 0.29/0.46/0.79 ms per 10^6 C2 pairs at gap 3/8/30 with (2,3,1), thread per pair 0.28/0.71/3.5) */
     int pack_gate = -1;                   /* 0 none, 1 behind NW, 2 behind LEAP; -1 = 1 with repack 2, 0 with repack 3 (ASM_PACK_GATE) */
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap = true;                  /* ASM_OVERLAP=0: everything on one stream */
@@ -676,6 +677,8 @@ int asm_create(asm_handle** out, int device) {
             HIPCHK(h, hipStreamCreateWithPriority(&h->pack_stream, hipStreamNonBlocking, atoi(pp) > 0 ? lo : hi));
         else
             HIPCHK(h, hipStreamCreateWithFlags(&h->pack_stream, hipStreamNonBlocking));
+        const char* sq = getenv("ASM_SIMD_QUAD");
+        if (sq) h->simd_quad_min = atoi(sq);
         const char* pg = getenv("ASM_PACK_GATE");
         if (pg) h->pack_gate = atoi(pg);
     }
@@ -1804,7 +1807,11 @@ int asm_simd_ed_affine_batch_async(asm_handle* h, const asm_batch* b, int gap_th
         out.out = d_ed;
         out.order = k.order;
         const dim3 grid((unsigned)((k.n + threads - 1) / threads)), block((unsigned)threads);
-        if (k.maxlen <= 128) {
+        if (k.maxlen <= 128 && gap_threshold >= h->simd_quad_min) { /* four threads per pair */
+            const size_t qlds = simd_quad_lds(gap_threshold, rg.gm, rg.gi);
+            hipLaunchKernelGGL(simd_ed_affine_quad_kernel, dim3((unsigned)((k.n + 15) / 16)), dim3(64), qlds, h->stream, k.planes, k.lens,
+                               (long)k.n, k.w4, gap_threshold, af_threshold, x, o, e, rg.gm, rg.gi, out);
+        } else if (k.maxlen <= 128) {
             if (lds > 64 * 1024)
                 HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&simd_ed_affine_kernel<2>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -300,6 +300,143 @@ __global__ __launch_bounds__(64) void simd_ed_affine_kernel(const uint4* __restr
     out.put(i, result == -2 ? -1 : result);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same recurrence with FOUR THREADS PER PAIR, sixteen pairs per wave, for strings of at most 128 characters (one 128-bit
+// half: none of the half-by-half shift effects of the 256-bit form) — the shape leap_quad_kernel gave LV::run (asm_wave.h):
+// the live lanes of a generation are dealt round-robin to the quad, rings [slot][lane row][pair] of bytes (end + 2 <= 130)
+// and the pair's four planes pair-major in LDS, each between two zero dwords so that the window of a shifted operand can start
+// up to 32 positions before the string (avx_away0 fills with zeros) and run past its end; a wave-scope fence between
+// generations.  Against one thread per pair the LDS a wave needs shrinks by four (gap 30, (2,3,1): 8 KB per wave instead of
+// 61), which is what bounds the occupancy there, and a wave waits for the slowest of 16 pairs instead of 64.
+// ---------------------------------------------------------------------------------------------------------------------
+#define SIMD_QUAD_PD 6 /* zero dword, 4 plane dwords, zero dword */
+#define SIMD_QUAD_PW (4 * SIMD_QUAD_PD + 1)
+ASM_DEV uint32_t simd_quad_window(const uint32_t* plane, int pos) { /* pos is already offset by the leading zero dword */
+    const int q = pos >> 5;
+    return __builtin_amdgcn_alignbit(plane[q + 1], plane[q], (uint32_t)(pos & 31));
+}
+// simd_extend(simd_lane_mask(d), st, len) on the LDS planes: d < 0 shifts the reference away from 0, d > 0 the read
+ASM_DEV int simd_quad_extend(const uint32_t* pl, int d, int st, int len) {
+    if (st >= len) return len;
+    const int s = d < 0 ? -d : d;
+    int apos = st + 32 - (d > 0 ? s : 0), bpos = st + 32 - (d < 0 ? s : 0), p = st;
+    for (;;) {
+        const uint32_t diff = (simd_quad_window(pl, apos) ^ simd_quad_window(pl + 2 * SIMD_QUAD_PD, bpos)) |
+                              (simd_quad_window(pl + SIMD_QUAD_PD, apos) ^ simd_quad_window(pl + 3 * SIMD_QUAD_PD, bpos));
+        if (diff) {
+            p += __builtin_ctz(diff);
+            break;
+        }
+        p += 32, apos += 32, bpos += 32;
+        if (p >= len) break;
+    }
+    return p < len ? p : len;
+}
+ASM_DEV int quad_min(int v) {
+    int w = __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false); /* quad_perm [1,0,3,2] */
+    v = w < v ? w : v;
+    w = __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false); /* quad_perm [2,3,0,1] */
+    return w < v ? w : v;
+}
+
+__global__ __launch_bounds__(64) void simd_ed_affine_quad_kernel(const uint4* __restrict__ planes, const uint32_t* __restrict__ lens,
+                                                                 long n, int w4, int T, int af_t, int x, int o, int ext, int gm,
+                                                                 int gi, OutMap out) {
+    constexpr int P = 16, PD = SIMD_QUAD_PD, PW = SIMD_QUAD_PW;
+    typedef uint8_t EnT;
+    extern __shared__ uint32_t s_afq[];
+    const int t = threadIdx.x, pr = t >> 2, q = t & 3;
+    const int rows = 2 * T + 3, mid = T + 1; /* lanes 1 .. 2T+1, guard rows 0 and 2T+2 (SIMD_ED.cpp:452-453) */
+    const int slot = rows * P;
+    const int ring_words = (int)(((size_t)(gm + 2 * gi) * slot * sizeof(EnT) + 3) / 4);
+    uint32_t* const pl = s_afq + pr * PW;                               /* [P][4][PD] (+1) */
+    EnT* const r_en = reinterpret_cast<EnT*>(s_afq + P * PW) + pr;    /* [gm][rows][P] */
+    EnT* const r_ip = r_en + gm * slot;                                 /* [gi][rows][P] */
+    EnT* const r_dp = r_ip + gi * slot;
+    {
+        uint32_t* const base = s_afq + P * PW;
+        for (int w = t; w < ring_words; w += 64) base[w] = 0u;
+    }
+    const long i = (long)blockIdx.x * P + pr;
+    const bool live = i < n;
+    int len = 0;
+    if (live) { /* thread q of the quad stages plane q: read plane 0/1, reference plane 0/1 */
+        const uint32_t ln = lens[i];
+        const int m = (int)(ln & 0xffffu), nn_ref = (int)(ln >> 16);
+        len = m > 128 ? 128 : m;
+        /* strncpy(A/B, ., length); the reference string ends at its own length (see simd_ed_affine_kernel) */
+        const int keep = q < 2 ? len : (nn_ref < len ? nn_ref : len);
+        const uint4 v = planes[((long)q * w4) * n + i];
+        const uint32_t d4[4] = {v.x, v.y, v.z, v.w};
+        uint32_t* dst = pl + q * PD;
+        dst[0] = 0u, dst[5] = 0u;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const int kb = keep - 32 * w;
+            dst[1 + w] = kb >= 32 ? d4[w] : (kb <= 0 ? 0u : (d4[w] & ((1u << kb) - 1u)));
+        }
+    }
+    leap_quad_fence();
+    int result = live ? -2 : 0; /* -2: still running */
+    if (live) { /* e = 0: only the main lane has a start (ED_GLOBAL, :474-477,497-516); the four threads compute the same value */
+        const int e0 = simd_quad_extend(pl, 0, 0, len);
+        if (q == 0) r_en[mid * P] = (EnT)(e0 + 2);
+        if (e0 == len) result = 1000000;
+    }
+    leap_quad_fence();
+    for (int e = 1; e <= af_t; e++) {
+        if (__ballot(result == -2) == 0ull) break;
+        int conv = 1000000;
+        if (result == -2) {
+            int dmax = e < o ? 0 : (e - o) / ext + 1; /* lanes a gap of this cost can have reached */
+            dmax = dmax > T ? T : dmax;
+            const EnT* const en_o = r_en + ((e - o) & (gm - 1)) * slot;
+            const EnT* const en_x = r_en + ((e - x) & (gm - 1)) * slot;
+            const EnT* const ip_e = r_ip + ((e - ext) & (gi - 1)) * slot;
+            const EnT* const dp_e = r_dp + ((e - ext) & (gi - 1)) * slot;
+            EnT* const en_w = r_en + (e & (gm - 1)) * slot;
+            EnT* const ip_w = r_ip + (e & (gi - 1)) * slot;
+            EnT* const dp_w = r_dp + (e & (gi - 1)) * slot;
+            for (int l = mid - dmax + q; l <= mid + dmax; l += 4) {
+                const int top = l >= mid ? 1 : 0, bot = l <= mid ? 1 : 0;
+                const int e_up = (int)en_o[(l - 1) * P] - 2, i_up = (int)ip_e[(l - 1) * P] - 2;
+                const int e_dn = (int)en_o[(l + 1) * P] - 2, d_dn = (int)dp_e[(l + 1) * P] - 2;
+                const int own = (int)en_x[l * P] - 2;
+                int inew = -2, dnew = -2;
+                if (e_up >= 0 && e_up > i_up)
+                    inew = e_up + top; /* :533-538 */
+                else if (i_up >= 0)
+                    inew = i_up + top; /* :539-544 */
+                if (e_dn >= 0 && e_dn > d_dn)
+                    dnew = e_dn + bot; /* :546-547 */
+                else if (d_dn >= 0)
+                    dnew = d_dn + bot; /* :548-549 */
+                int st = own >= 0 ? own + 1 : -2; /* :551-558 */
+                st = inew > st ? inew : st;
+                st = dnew > st ? dnew : st;
+                int enew = -2;
+                if (st >= 0) {
+                    enew = simd_quad_extend(pl, l - mid, st, len); /* :579-581 */
+                    if (enew == len) { /* :589-603 */
+                        const int diff = l < mid ? mid - l : l - mid;
+                        const int tc = e + (diff ? o + (diff - 1) * ext : 0);
+                        if (tc <= af_t && tc < conv) conv = tc;
+                    }
+                }
+                en_w[l * P] = (EnT)(enew + 2), ip_w[l * P] = (EnT)(inew + 2), dp_w[l * P] = (EnT)(dnew + 2);
+            }
+        }
+        conv = quad_min(conv);
+        if (conv != 1000000 && result == -2) result = conv; /* ED_pass: the generation loop ends (:609-610) */
+        leap_quad_fence();
+    }
+    if (live && q == 0) out.put(i, result == -2 ? -1 : result);
+}
+
+static inline size_t simd_quad_lds(int T, int gm, int gi) {
+    return (size_t)16 * SIMD_QUAD_PW * sizeof(uint32_t) + (((size_t)(gm + 2 * gi) * (2 * T + 3) * 16 + 3) & ~(size_t)3);
+}
+
 // clean mode: every pair judged alone — never reached: fail; exact: 0; reached: final_ED + lane distance if <= T
 __global__ __launch_bounds__(ASM_BLOCK) void simd_ed_clean_kernel(int32_t* __restrict__ ev_to_ed, long n, int T) {
     const long i = (long)blockIdx.x * ASM_BLOCK + threadIdx.x;

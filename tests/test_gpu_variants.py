@@ -45,6 +45,8 @@ for wl, n, k in (("C2", 12000, 3), ("C5", 6000, 3), ("C3", 1500, 30), ("C2", 200
         check(wl + " nw affine", eng.align(bc, asm.NW, pg), orc.nw(hb, 2, 3, 1))
         check(wl + " leap general", eng.align(bc, asm.LEAP, pg), orc.leap(hb, k, 2, 3, 1))
         check(wl + " greedy general", eng.align(bc, asm.GREEDY, pg), orc.greedy(hb, k, 2, 3, 1, mode=1))
+        for g, af in ((3, 40), (9, 70)):
+            check(wl + " simd_ed affine", eng.simd_ed_affine(bc, g, af, 2, 3, 1), orc.simd_ed_affine(hb, g, af, 2, 3, 1)[0])
 print("ok")
 """ % ROOT
 
@@ -66,6 +68,8 @@ print("ok")
     {"ASM_LEAP_SORT": "0"},
     {"ASM_LEAP_QUAD": "0", "ASM_LEAP_BAND": "0"},
     {"ASM_BUCKET": "0"},
+    {"ASM_SIMD_QUAD": "1"},
+    {"ASM_SIMD_QUAD": "100"},
     {"ASM_REFILL_GREEDY": "1", "ASM_REFILL_LEAP": "64", "ASM_PERSIST_LEAP": "1", "ASM_LEAP_HINT": "0"},
 ])
 def test_alternative_kernels_match_the_oracle(env):
