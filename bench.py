@@ -163,6 +163,7 @@ def parse_args():
                     help="strong scaling: this many pairs in total, split into contiguous shards over the ranks "
                          "(e.g. --workload C4 --total-pairs 10000000); default is weak scaling with --pairs per GPU")
     ap.add_argument("--cpu-sample", type=int, default=300_000)
+    ap.add_argument("--no-in-order", action="store_true", help="skip the extra in-order leg (ms_per_step_in_order)")
     ap.add_argument("--no-standalone", action="store_true",
                     help="skip the separately instrumented stand-alone kernel pass (profiling runs: every launch is a timed-region launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -369,7 +370,7 @@ def run(args, asm, eng, torch, dist, stream, rank, world, cfg, params, first, n,
 
     # the same K steps strictly in order (repack = 1), for the record: what a caller without a second batch in flight gets
     in_order_ms = None
-    if PACK_MODE != 1:
+    if PACK_MODE != 1 and not args.no_in_order:
         scratch_cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
         k_in = min(args.steps, 20)
         barrier()

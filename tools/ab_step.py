@@ -13,7 +13,7 @@ for r in range(rounds):
             k, v = kv.split("=", 1)
             env[k] = v
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "5", "--no-cpu-baseline",
-                              "--no-sequential", "--no-standalone"], env=env, capture_output=True, text=True, timeout=300)
+                              "--no-sequential", "--no-standalone", "--no-in-order"], env=env, capture_output=True, text=True, timeout=300)
         d = json.loads(out.stdout.strip().splitlines()[-1])
         res[c].append(d["ms_per_step"])
         print(f"round {r} [{c}] {d['ms_per_step']:.4f}", flush=True)

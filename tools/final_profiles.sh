@@ -15,7 +15,7 @@ cd $R
 python3 tools/pmc_collect.py --head $HEAD > $O/pmc_collect.log 2>&1
 echo "pmc_collect done"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o c2 -- python3 $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-standalone --no-sequential > $O/stats_bench.json 2> $O/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o c2 -- python3 $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-standalone --no-sequential --no-in-order > $O/stats_bench.json 2> $O/stats.err
 echo "kernel stats done"
 cd $R
 python3 bench.py > $O/bench.json 2> $O/bench.err

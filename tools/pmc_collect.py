@@ -161,7 +161,7 @@ def main():
     out_dir = os.path.join(ROOT, "gpurun_out", "final", "pmc")
     os.makedirs(out_dir, exist_ok=True)
     bench_args = ["--workload", args.workload, "--steps", str(args.steps), "--warmup", "1", "--no-cpu-baseline",
-                  "--no-sequential", "--no-standalone"] + (["--pairs", str(args.pairs)] if args.pairs else [])
+                  "--no-sequential", "--no-standalone", "--no-in-order"] + (["--pairs", str(args.pairs)] if args.pairs else [])
     data = {name: run_pass(name, ctrs, out_dir, bench_args) for name, ctrs in PASSES.items()}
 
     import approximate_string_matching_amd as asm
