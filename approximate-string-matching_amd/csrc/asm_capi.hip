@@ -64,7 +64,7 @@ struct asm_handle {
                                              2.8x SLOWER than the wave-per-pair kernel at C3 — a wave pays for its unluckiest thread
                                              (DESIGN.md section 7).  ASM_GREEDY_PRUNE=<k> switches it on from k up */
     int prune_waves = 8;                  /* its waves per CU (ASM_PRUNE_WAVES: 4, 8, 12, 16; LDS holds 160 B per thread) */
-    int g3_prio = 0;                      /* ASM_GREEDY_PRIO (experiment: s_setprio turns; no effect measured) */
+    int g3_park = 0;                      /* ASM_GREEDY_PARK: drain compaction of the fast Greedy kernel (asm_greedy3_kernel.h) */
     int g3_waves = 2;                     /* resident waves per SIMD of the fast Greedy kernel (ASM_GREEDY_WAVES = 1, 2, 3) */
     int persist_waves = 0;                /* cap on the resident waves per SIMD of the persistent kernels (ASM_PERSIST_WAVES; 0 = what fits) */
     bool greedy_fast = true;              /* Greedy, k <= 3, unit penalties, GLOBAL: the straight-line pass with integer rank keys
@@ -309,7 +309,7 @@ static hipError_t launch_greedy_fast_nt(asm_handle* h, const asm_bucket& b, cons
     if (blocks > need) blocks = need;
     const G3Sig sig = {ga.sig_match, ga.sig_mismatch, ga.sig_indel};
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NT), lds, h->stream, (const uint4*)b.planes, (const uint32_t*)b.lens,
-                       (long)b.n, b.w4, sig, (const uint2*)h->d_g3_table, out, cig, h->refill_greedy, h->g3_prio);
+                       (long)b.n, b.w4, sig, (const uint2*)h->d_g3_table, out, cig, h->refill_greedy, h->g3_park);
     return hipGetLastError();
 }
 template <int K>
@@ -714,7 +714,7 @@ int asm_create(asm_handle** out, int device) {
     if ((env = getenv("ASM_REFILL_GREEDY"))) h->refill_greedy = atoi(env);
     if ((env = getenv("ASM_GREEDY_FAST"))) h->greedy_fast = env[0] != '0';
     if ((env = getenv("ASM_PERSIST_WAVES"))) h->persist_waves = atoi(env);
-    if ((env = getenv("ASM_GREEDY_PRIO"))) h->g3_prio = atoi(env);
+    if ((env = getenv("ASM_GREEDY_PARK"))) h->g3_park = atoi(env);
     if ((env = getenv("ASM_GREEDY_PRUNE"))) h->greedy_prune = atoi(env);
     if ((env = getenv("ASM_PRUNE_WAVES"))) h->prune_waves = atoi(env);
     if ((env = getenv("ASM_GREEDY_WAVES"))) h->g3_waves = atoi(env);

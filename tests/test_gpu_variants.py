@@ -57,6 +57,9 @@ print("ok")
     {"ASM_GREEDY_PRUNE": "6", "ASM_PERSIST_WIDE": "0"},
     {"ASM_GREEDY_PRUNE": "17", "ASM_PRUNE_WAVES": "16"},
     {"ASM_GREEDY_WAVES": "3"},
+    {"ASM_GREEDY_PARK": "1"},
+    {"ASM_GREEDY_PARK": "1", "ASM_GREEDY_WAVES": "3", "ASM_REFILL_GREEDY": "24"},
+    {"ASM_GREEDY_PARK": "0"},
     {"ASM_GREEDY_WAVES": "1", "ASM_REFILL_GREEDY": "1"},
     {"ASM_PERSIST_LEAP": "1", "ASM_LEAP_HINT": "0"},
     {"ASM_LEAP_HINT": "0"},
