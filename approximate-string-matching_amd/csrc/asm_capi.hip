@@ -42,6 +42,8 @@ struct asm_handle {
     hipStream_t side_stream = nullptr;    /* asm_run_benchmark_async runs Greedy beside the NW -> LEAP chain */
     hipStream_t pack_stream = nullptr;    /* ... and, with repack = 2, packs for this call while the previous call still aligns */
     hipEvent_t ev_packed = nullptr;
+    hipEvent_t ev_nw = nullptr;
+    int leap_own = 1;                     /* repack = 3: LEAP runs on acc_stream, behind the NW of its call and beside the NW of the next (ASM_LEAP_STREAM=0: behind NW on the caller's stream) */
     hipStream_t acc_stream = nullptr;     /* repack = 3: the counters of a call, behind both of its chains */
     hipEvent_t ev_leap = nullptr, ev_tail = nullptr;
     bool tail_set = false;
@@ -685,6 +687,8 @@ int asm_create(asm_handle** out, int device) {
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_packed, hipEventDisableTiming));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_gate, hipEventDisableTiming));
     HIPCHK(h, hipStreamCreateWithFlags(&h->acc_stream, hipStreamNonBlocking));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_nw, hipEventDisableTiming));
+    if (getenv("ASM_LEAP_STREAM")) h->leap_own = atoi(getenv("ASM_LEAP_STREAM"));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_leap, hipEventDisableTiming));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_tail, hipEventDisableTiming));
     for (hipEvent_t& ev : h->ev_out) HIPCHK(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -750,6 +754,7 @@ int asm_destroy(asm_handle* h) {
     for (hipEvent_t ev : h->ev_out)
         if (ev) (void)hipEventDestroy(ev);
     if (h->acc_stream) (void)hipStreamDestroy(h->acc_stream);
+    if (h->ev_nw) (void)hipEventDestroy(h->ev_nw);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->d_todo) (void)hipFree(h->d_todo);
@@ -2028,18 +2033,29 @@ int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, in
                 h->gate_set = true;
             }
         }
+        /* LEAP on the counters' stream when there is an NW to wait for: the next call's NW then follows this call's NW directly,
+         * and the chain on that stream is LEAP -> counters -> LEAP.  (The HIP runtime spreads streams over four hardware queues:
+         * a fifth busy stream shares a queue with another and serialises with it — measured 0.26-0.29 ms per step —, so LEAP
+         * gets no stream of its own.) */
+        hipStream_t ls = (h->leap_own && d_nw && d_leap) ? h->acc_stream : main_stream;
         if (!rc && d_leap) {
-            PROF(2, 0, main_stream)
+            if (ls != main_stream) {
+                HIPCHK(h, hipEventRecord(h->ev_nw, main_stream));
+                HIPCHK(h, hipStreamWaitEvent(ls, h->ev_nw, 0));
+            }
+            PROF(2, 0, ls)
+            h->stream = ls;
             rc = asm_align_batch_hinted_async(h, b, ASM_LEAP, p, d_nw, d_leap);
-            PROF(2, 1, main_stream)
+            h->stream = main_stream;
+            PROF(2, 1, ls)
             if (!rc && h->pack_gate == 2) { /* (explicit ASM_PACK_GATE only) */
-                HIPCHK(h, hipEventRecord(h->ev_gate, main_stream));
+                HIPCHK(h, hipEventRecord(h->ev_gate, ls));
                 h->gate_set = true;
             }
         }
         if (pe) h->prof_mask.push_back(pmask);
         if (rc) return rc;
-        HIPCHK(h, hipEventRecord(h->ev_leap, main_stream));
+        HIPCHK(h, hipEventRecord(h->ev_leap, ls));
         HIPCHK(h, hipStreamWaitEvent(h->acc_stream, h->ev_leap, 0));
         if (d_greedy) HIPCHK(h, hipStreamWaitEvent(h->acc_stream, h->ev_join, 0));
         if (d_counters && d_nw) {

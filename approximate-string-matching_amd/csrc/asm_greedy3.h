@@ -48,7 +48,9 @@ typedef unsigned long long g3_u64;
 #define G3_MARK(name)
 #endif
 
+#ifndef G3_TMAX
 #define G3_TMAX 64  /* table domain: hurdles + switches < G3_TMAX */
+#endif
 #define G3_LENS 129 /* highway lengths 0..128 */
 #define G3_TABLE_ENTRIES (G3_LENS * G3_TMAX)
 #define G3_INF 0xffffffffu
