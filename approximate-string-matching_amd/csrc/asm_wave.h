@@ -844,16 +844,26 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_wave_kernel(const uint4* __r
             // keys and three 32-bit wave max-reductions
             heur = heur + 0.0; /* -0.0 -> +0.0 so that equal values have equal keys */
             const unsigned long long hb = (unsigned long long)__double_as_longlong(heur);
-            const unsigned long long key = (hb >> 63) ? ~hb : (hb | 0x8000000000000000ull);
-            unsigned khi = active ? (unsigned)(key >> 32) : 0u;
+            // key = hb < 0 ? ~hb : hb | 2^63, word by word (the lower word is only needed when the upper words tie)
+            const unsigned hhi = (unsigned)(hb >> 32);
+            const unsigned sgn = (unsigned)((int)hhi >> 31); /* all ones for a negative score */
+            unsigned khi = active ? ((hhi ^ sgn) | (~sgn & 0x80000000u)) : 0u;
             const unsigned mhi = wave_max_u32(khi);
             bool cand = active && khi == mhi;
-            const unsigned klo = cand ? (unsigned)key : 0u;
-            const unsigned mlo = wave_max_u32(klo);
-            cand = cand && klo == mlo;
-            const unsigned k3 = cand ? ((((unsigned)(leap + 32768)) << 6) | (unsigned)(63 - t)) : 0u;
-            const unsigned m3 = wave_max_u32(k3);
-            const int bt = 63 - (int)(m3 & 63u); /* wave-uniform winner */
+            // Usually one lane alone holds the maximum already in the upper word (scores of different (length, hurdles) differ
+            // by far more than 2^-20 relative; ties are lanes of one class): the other two reductions are skipped then
+            const unsigned long long cm = __ballot(cand);
+            int bt;
+            if ((cm & (cm - 1ull)) == 0ull) { /* wave-uniform; cm != 0: some active lane holds the maximum */
+                bt = __builtin_ctzll(cm);
+            } else {
+                const unsigned klo = cand ? ((unsigned)hb ^ sgn) : 0u;
+                const unsigned mlo = wave_max_u32(klo);
+                cand = cand && klo == mlo;
+                const unsigned k3 = cand ? ((((unsigned)(leap + 32768)) << 6) | (unsigned)(63 - t)) : 0u;
+                const unsigned m3 = wave_max_u32(k3);
+                bt = 63 - (int)(m3 & 63u); /* wave-uniform winner */
+            }
             const int best = bt - k;
             const int best_sp = lane_read(sp, bt), best_len = lane_read(len, bt);
             const int best_cost = lane_read(sw + hc, bt);
