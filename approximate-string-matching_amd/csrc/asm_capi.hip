@@ -1834,6 +1834,30 @@ int asm_simd_ed_affine_batch_async(asm_handle* h, const asm_batch* b, int gap_th
     return ASM_OK;
 }
 
+int asm_simd_ed_affine_shd_batch_async(asm_handle* h, const asm_batch* b, int gap_threshold, int af_threshold, int x, int o, int e,
+                                       int shd_threshold, int32_t* d_ed) {
+    if (shd_threshold < 0 || shd_threshold > ASM_SHD_MAX_ERROR || shd_threshold > gap_threshold)
+        return fail(h, ASM_EINVAL, "asm_simd_ed_affine_shd_batch_async: SHD threshold must be in [0, min(16, gap threshold)] "
+                                   "(the reference reads 2*SHD_threshold+1 of its 2*gap_threshold+1 lane masks)");
+    const int rc = asm_simd_ed_affine_batch_async(h, b, gap_threshold, af_threshold, x, o, e, d_ed);
+    if (rc != ASM_OK || b->n == 0) return rc;
+    for (int q = 0; q < b->nb; q++) {
+        const asm_bucket& k = b->bk[q];
+        OutMap out;
+        out.out = d_ed;
+        out.order = k.order;
+        const dim3 g(grid_for(k.n)), t(ASM_BLOCK);
+        if (k.maxlen <= 128)
+            hipLaunchKernelGGL(simd_affine_shd_kernel<2>, g, t, 0, h->stream, k.planes, k.lens, (long)k.n, k.w4, gap_threshold,
+                               shd_threshold, out);
+        else
+            hipLaunchKernelGGL(simd_affine_shd_kernel<4>, g, t, 0, h->stream, k.planes, k.lens, (long)k.n, k.w4, gap_threshold,
+                               shd_threshold, out);
+    }
+    HIPCHK(h, hipGetLastError());
+    return ASM_OK;
+}
+
 int asm_shd_filter_batch_async(asm_handle* h, const asm_batch* b, int max_error, int32_t* d_pass) {
     if (!h || !b || !d_pass) return fail(h, ASM_EINVAL, "asm_shd_filter_batch_async: NULL argument");
     if (max_error < 0 || max_error > ASM_SHD_MAX_ERROR)

@@ -437,6 +437,34 @@ static inline size_t simd_quad_lds(int T, int gm, int gi) {
     return (size_t)16 * SIMD_QUAD_PW * sizeof(uint32_t) + (((size_t)(gm + 2 * gi) * (2 * T + 3) * 16 + 3) & ~(size_t)3);
 }
 
+// init_affine's SHD_enable / SHD_threshold (SIMD_ED.cpp:435,445-446): run_affine starts with bit_vec_filter_avx(hamming_masks + 1,
+// buffer_length, SHD_threshold) (:489-492), the mask-array filter of simd_ed_kernel (S3) over the FIRST 2*SHD_threshold+1 lane
+// masks — lanes -gap .. -gap + 2*SHD_threshold, each cut by the begin mask of |j - SHD_threshold|: centred on the main lane only
+// when SHD_threshold equals the gap threshold.  A rejected pair does not pass and nothing else changes, so this runs as a
+// second, cheap kernel behind the affine one and overwrites the verdicts of the pairs it rejects.
+template <int W64>
+__global__ __launch_bounds__(ASM_BLOCK) void simd_affine_shd_kernel(const uint4* __restrict__ planes, const uint32_t* __restrict__ lens,
+                                                                    long n, int w4, int gap_t, int shd_t, OutMap out) {
+    const long i = (long)blockIdx.x * ASM_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int m = (int)(lens[i] & 0xffffu), nn_ref = (int)(lens[i] >> 16);
+    const int len = m > 64 * W64 ? 64 * W64 : m;
+    VW<W64> A0, A1, B0, B1;
+    load_planes<W64>(planes, n, w4, i, A0, A1, B0, B1);
+    const VW<W64> lm = vw_low_ones<W64>(len), lb = vw_low_ones<W64>(nn_ref < len ? nn_ref : len);
+#pragma unroll
+    for (int q = 0; q < W64; q++) A0.w[q] &= lm.w[q], A1.w[q] &= lm.w[q], B0.w[q] &= lb.w[q], B1.w[q] &= lb.w[q];
+    VW<W64> diff = lm;
+    for (int j = 0; j <= 2 * shd_t; j++) {
+        const int s = j < shd_t ? shd_t - j : j - shd_t;
+        const VW<W64> tm = s ? vw_from<W64>(s) : vw_low_ones<W64>(255);
+        const VW<W64> h = simd_lane_mask<W64>(A0, A1, B0, B1, j - gap_t);
+#pragma unroll
+        for (int q = 0; q < W64; q++) diff.w[q] &= h.w[q] & tm.w[q];
+    }
+    if (shd_popcount<W64>(diff) > shd_t) out.put(i, -1);
+}
+
 // clean mode: every pair judged alone — never reached: fail; exact: 0; reached: final_ED + lane distance if <= T
 __global__ __launch_bounds__(ASM_BLOCK) void simd_ed_clean_kernel(int32_t* __restrict__ ev_to_ed, long n, int T) {
     const long i = (long)blockIdx.x * ASM_BLOCK + threadIdx.x;

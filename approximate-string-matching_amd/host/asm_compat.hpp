@@ -156,6 +156,8 @@ class SIMD_ED {
     bool shd_ = true;
     bool affine_ = false;
     int gap_t_ = 0, af_t_ = 0, x_ = 1, o_ = 1, e_ = 1;
+    bool af_shd_ = false;
+    int af_shd_t_ = 0;
     int32_t state_[3] = {0, 0, 0};
     std::string read_, ref_;
     int ed_ = -1;
@@ -164,10 +166,10 @@ public:
     // SIMD_ED.h:50 / SIMD_ED.cpp:435-616.  CLEAN form: run() judges the pair from the tables init_affine leaves, whatever ran
     // before (the reference object re-uses the tables of the pair before; see asm_simd_ed_affine_batch_async).
     void init_affine(int gap_threshold, int AF_threshold, ED_modes mode, int ms_penalty, int gap_open_penalty, int gap_ext_penalty,
-                     bool SHD_enable = false, int /*SHD_threshold*/ = 10) {
+                     bool SHD_enable = false, int SHD_threshold = 10) {
         if (mode != ED_GLOBAL) throw std::runtime_error("SIMD_ED::init_affine: the accelerated path is ED_GLOBAL");
-        if (SHD_enable) throw std::runtime_error("SIMD_ED::init_affine: SHD inside the affine mode is not accelerated (default: off)");
         affine_ = true, gap_t_ = gap_threshold, af_t_ = AF_threshold, x_ = ms_penalty, o_ = gap_open_penalty, e_ = gap_ext_penalty;
+        af_shd_ = SHD_enable, af_shd_t_ = SHD_threshold; /* run_affine's SHD over the first 2*SHD_threshold+1 lane masks (:489-492) */
     }
     void init_levenshtein(int ED_threshold, ED_modes mode = ED_GLOBAL, bool SHD_enable = true) {
         if (mode != ED_GLOBAL) throw std::runtime_error("SIMD_ED::init_levenshtein: the accelerated path is ED_GLOBAL (main.cpp:97)");
@@ -188,7 +190,8 @@ public:
         int32_t out = -1;
         check(h, asm_batch_upload(h, 1, read_.data(), ro, ref_.data(), fo, ASM_GREEDY_CLEAN, &b));
         check(h, asm_device_malloc(h, sizeof(int32_t), &d));
-        const int rc = affine_ ? asm_simd_ed_affine_batch_async(h, b, gap_t_, af_t_, x_, o_, e_, (int32_t*)d)
+        const int rc = affine_ ? (af_shd_ ? asm_simd_ed_affine_shd_batch_async(h, b, gap_t_, af_t_, x_, o_, e_, af_shd_t_, (int32_t*)d)
+                                          : asm_simd_ed_affine_batch_async(h, b, gap_t_, af_t_, x_, o_, e_, (int32_t*)d))
                                : asm_simd_ed_batch_async(h, b, ed_t_, shd_ ? 1 : 0, ASM_FILTER_SEQUENTIAL, state_, (int32_t*)d);
         if (rc == ASM_OK) check(h, asm_memcpy_d2h(h, &out, d, sizeof(int32_t)));
         asm_device_free(h, d);

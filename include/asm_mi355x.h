@@ -246,6 +246,13 @@ int asm_simd_ed_batch_async(asm_handle* h, const asm_batch* b, int ed_threshold,
  * [1, 512], 1 <= e <= o <= 15, 1 <= x <= 15; SHD off (init_affine's default).  Enqueue only. */
 int asm_simd_ed_affine_batch_async(asm_handle* h, const asm_batch* b, int gap_threshold, int af_threshold, int x, int o, int e,
                                    int32_t* d_ed);
+/* The same with init_affine's SHD_enable = true and SHD_threshold (LEAP_SIMD/SIMD_ED.h:50, SIMD_ED.cpp:445-446,489-492):
+ * run_affine starts with bit_vec_filter_avx(hamming_masks + 1, buffer_length, SHD_threshold) — the mask-array SHD
+ * (SHD.cpp:334-372) over the first 2*SHD_threshold+1 lane masks, i.e. lanes -gap .. -gap + 2*SHD_threshold (centred on the main
+ * lane only when the two thresholds are equal) — and a rejected pair does not pass (d_ed[i] = -1).  shd_threshold in
+ * [0, min(16, gap_threshold)]: the reference object holds 2*gap_threshold+1 masks and would read past them.  Enqueue only. */
+int asm_simd_ed_affine_shd_batch_async(asm_handle* h, const asm_batch* b, int gap_threshold, int af_threshold, int x, int o, int e,
+                                       int shd_threshold, int32_t* d_ed);
 /* bit_vec_filter_avx(read planes, ref planes, min(m, 256), max_error) (LEAP_SIMD/SHD.h:17-18, SHD.cpp:241-322):
  * d_pass[i] = 1 when the pair survives the shifted-Hamming-distance filter, 0 when it is rejected.  max_error in
  * [0, 16].  Enqueue only. */

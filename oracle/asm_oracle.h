@@ -103,6 +103,9 @@ int orc_simd_ed_batch(int64_t n, const char* reads, const uint32_t* read_off, co
 /* SIMD_ED affine mode, clean (every pair from init_affine's tables): ed[i] = get_ED() if the pair passes, else -1 */
 int orc_simd_ed_affine_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
                              int gap_t, int af_t, int x, int o, int ext, int32_t* ed, uint8_t* pass);
+/* ... with init_affine's SHD_enable / SHD_threshold (shd_t <= gap_t, <= 16): the mask-array SHD in front of run_affine */
+int orc_simd_ed_affine_shd_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
+                                 int gap_t, int af_t, int x, int o, int ext, int shd_enable, int shd_t, int32_t* ed, uint8_t* pass);
 
 int orc_shd_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
                   int max_error, int32_t* pass);

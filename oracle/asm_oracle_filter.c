@@ -260,7 +260,18 @@ int orc_simd_ed_batch(int64_t n, const char* reads, const uint32_t* read_off, co
 #define SIMD_AF_MAX 512
 int orc_simd_ed_affine_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
                              int gap_t, int af_t, int x, int o, int ext, int32_t* ed, uint8_t* pass) {
+    return orc_simd_ed_affine_shd_batch(n, reads, read_off, refs, ref_off, gap_t, af_t, x, o, ext, 0, 0, ed, pass);
+}
+
+/* The same with init_affine's last two arguments (SHD_enable, SHD_threshold; SIMD_ED.cpp:435,445-446): run_affine starts with
+ * bit_vec_filter_avx(hamming_masks + 1, buffer_length, SHD_threshold) (:489-492) — the mask-array filter of SHD.cpp:334-372
+ * over the FIRST 2*SHD_threshold+1 lane masks, j = 0 .. 2*SHD_threshold, each cut by the begin mask of |j - SHD_threshold|.
+ * Those are the lanes -gap_t .. -gap_t + 2*SHD_threshold: centred on the main lane only when SHD_threshold == gap_t, and
+ * beyond the object's array when it is larger (refused here).  A rejected pair does not pass; nothing else changes. */
+int orc_simd_ed_affine_shd_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
+                                 int gap_t, int af_t, int x, int o, int ext, int shd_enable, int shd_t, int32_t* ed, uint8_t* pass) {
     if (gap_t < 1 || gap_t > SIMD_MAX_T || af_t < 1 || af_t > SIMD_AF_MAX || x < 1 || o < 1 || ext < 1) return -1;
+    if (shd_enable && (shd_t < 0 || shd_t > gap_t || shd_t > 16)) return -1;
     const int lanes = 2 * gap_t + 3, mid = gap_t + 1; /* SIMD_ED.cpp:452-453 */
     v256 hm[2 * SIMD_MAX_T + 3];
     typedef int row_t[SIMD_AF_MAX + 1];
@@ -278,6 +289,19 @@ int orc_simd_ed_affine_batch(int64_t n, const char* reads, const uint32_t* read_
             const v256 x0 = l > mid ? avx_shr(a0, s) : a0, x1 = l > mid ? avx_shr(a1, s) : a1;
             const v256 y0 = l < mid ? avx_shr(b0, s) : b0, y1 = l < mid ? avx_shr(b1, s) : b1;
             hm[l] = v_or(v_xor(x0, y0), v_xor(x1, y1));
+        }
+        if (shd_enable) { /* :489-492; the filter as in orc_simd_ed_batch (S3), over masks hm[1 + j] */
+            const v256 lm = low_ones(len >= 256 ? 256 : len);
+            v256 diff = low_ones(256);
+            for (int j = 0; j <= 2 * shd_t; j++) {
+                const int s = abs(j - shd_t);
+                const v256 tm = v_and(s ? not_low_ones(s) : low_ones(255), lm);
+                diff = v_and(diff, v_and(hm[1 + j], tm));
+            }
+            if (popcount_shd(diff) > shd_t) {
+                pass[i] = 0, ed[i] = -1;
+                continue;
+            }
         }
         for (int l = 0; l < lanes; l++) /* init_affine, :467-478 */
             for (int e = 0; e <= af_t; e++) start[l][e] = end[l][e] = ip[l][e] = dp[l][e] = -2;

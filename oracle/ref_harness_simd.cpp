@@ -53,8 +53,15 @@ int ref_simd_ed_batch(int64_t n, const char* reads, const uint32_t* read_off, co
 
 // Affine mode, CLEAN: init_affine before every pair (it destroys and rebuilds the tables: -2 everywhere, start[mid][0] = 0), so
 // that no pair sees the tables of the one before; ed[i] = get_ED(), pass[i] = check_pass().
+int ref_simd_ed_affine_shd_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
+                                 int gap_t, int af_t, int x, int o, int e, int shd_enable, int shd_t, int32_t* ed, uint8_t* pass);
 int ref_simd_ed_affine_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
                              int gap_t, int af_t, int x, int o, int e, int32_t* ed, uint8_t* pass) {
+    return ref_simd_ed_affine_shd_batch(n, reads, read_off, refs, ref_off, gap_t, af_t, x, o, e, 0, 0, ed, pass);
+}
+// ... with init_affine's SHD_enable / SHD_threshold (SIMD_ED.h:50)
+int ref_simd_ed_affine_shd_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
+                                 int gap_t, int af_t, int x, int o, int e, int shd_enable, int shd_t, int32_t* ed, uint8_t* pass) {
     SIMD_ED* obj = new SIMD_ED;
     std::string s1, s2;
     for (int64_t i = 0; i < n; i++) {
@@ -63,7 +70,7 @@ int ref_simd_ed_affine_batch(int64_t n, const char* reads, const uint32_t* read_
         s1.assign(reads + read_off[i], m);
         s2.assign(refs + ref_off[i], nn);
         int length = m > 256 ? 256 : m;
-        obj->init_affine(gap_t, af_t, ED_GLOBAL, x, o, e);
+        obj->init_affine(gap_t, af_t, ED_GLOBAL, x, o, e, shd_enable != 0, shd_t);
         obj->load_reads((char*)s1.c_str(), (char*)s2.c_str(), length);
         obj->calculate_masks();
         obj->reset(); /* -> reset_affine / run_affine: affine_mode is set by init_affine */

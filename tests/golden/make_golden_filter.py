@@ -24,6 +24,8 @@ SIMD_SETTINGS = [(1, 1), (2, 0), (3, 1), (3, 0), (5, 1), (8, 0), (12, 1), (16, 1
 SHD_ERRORS = [0, 1, 3, 5, 9, 16]
 # affine mode, clean (init_affine before every pair): (gap threshold, affine threshold, x, o, e)
 AFFINE_SETTINGS = [(3, 60, 2, 3, 1), (5, 40, 1, 1, 1), (8, 100, 4, 6, 2), (2, 30, 3, 5, 2), (10, 25, 1, 2, 1)]
+# ... with init_affine's SHD_enable = true: (gap threshold, affine threshold, x, o, e, SHD threshold)
+AFFINE_SHD_SETTINGS = [(3, 60, 2, 3, 1, 3), (6, 30, 1, 1, 1, 2), (12, 120, 4, 6, 2, 5), (16, 90, 2, 3, 1, 16)]
 
 
 def main():
@@ -43,11 +45,15 @@ def main():
             ed, ps = ref.simd_ed_affine(hb, g, af, x, o, e)
             out[f"af_pass_g{g}_a{af}_x{x}o{o}e{e}"] = ps.astype(np.uint8)
             out[f"af_ed_g{g}_a{af}_x{x}o{o}e{e}"] = ed.astype(np.int32)
+        for g, af, x, o, e, st in AFFINE_SHD_SETTINGS:
+            ed, ps = ref.simd_ed_affine(hb, g, af, x, o, e, shd_t=st)
+            out[f"afs_pass_g{g}_a{af}_x{x}o{o}e{e}_s{st}"] = ps.astype(np.uint8)
+            out[f"afs_ed_g{g}_a{af}_x{x}o{o}e{e}_s{st}"] = ed.astype(np.int32)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
         index[name] = {"workload": wl, "first": first, "n": n, "inputs_sha256": inputs_sha(hb)}
         print(name, {k: float(v.mean()) for k, v in out.items() if k.startswith("pass")})
     with open(os.path.join(HERE, "filter_index.json"), "w") as fh:
-        json.dump({"cases": index, "simd_settings": SIMD_SETTINGS, "shd_errors": SHD_ERRORS, "affine_settings": AFFINE_SETTINGS,
+        json.dump({"cases": index, "simd_settings": SIMD_SETTINGS, "shd_errors": SHD_ERRORS, "affine_settings": AFFINE_SETTINGS, "affine_shd_settings": AFFINE_SHD_SETTINGS,
                    "warm_state": list(oracle_binding.SIMD_WARM_STATE)}, fh, indent=1, sort_keys=True)
 
 

@@ -562,6 +562,27 @@ def test_simd_ed_affine_filter_matches_oracle(asm, engine, oracle, wl, n, settin
     assert bad.size == 0, (wl, setting, bad[:5], got[bad[:5]], want[bad[:5]])
 
 
+@pytest.mark.parametrize("wl,n", [("C2", 12000), ("C5", 9000), ("C3", 4000)])
+@pytest.mark.parametrize("setting", [(3, 60, 2, 3, 1, 3), (6, 30, 1, 1, 1, 2), (12, 120, 4, 6, 2, 5), (16, 90, 2, 3, 1, 16), (20, 40, 1, 2, 1, 0)])
+def test_simd_ed_affine_filter_with_shd_matches_oracle(asm, engine, oracle, wl, n, setting):
+    """init_affine(..., SHD_enable = true, SHD_threshold): the mask-array SHD in front of run_affine, over the first
+    2*SHD_threshold+1 lane masks (centred on the main lane only when the thresholds are equal); both kernel forms (four threads
+    per pair up to 128 characters, thread per pair beyond) and argument errors."""
+    g, af, x, o, e, st = setting
+    cfg, _, _ = asm.workload(wl)
+    hb = asm.generate_pairs(cfg, 47, n)
+    batch = engine.upload(hb, asm.GREEDY_CLEAN)
+    want, _ = oracle.simd_ed_affine(hb, g, af, x, o, e, shd_t=st)
+    got = engine.simd_ed_affine(batch, g, af, x, o, e, shd_threshold=st)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, (wl, setting, bad[:5], got[bad[:5]], want[bad[:5]])
+    for bad_t in (-1, g + 1, 17):
+        if bad_t <= g and 0 <= bad_t <= 16:
+            continue
+        with pytest.raises(asm.AsmError):
+            engine.simd_ed_affine(batch, g, af, x, o, e, shd_threshold=bad_t)
+
+
 def test_filters_ignore_the_stale_tails_of_sequential_batches(asm, engine, oracle):
     """A batch packed for Greedy's sequential mode keeps the reference's stale buffer tails beyond each string's end; NW, LEAP
     and the three filters must not see them (mixed lengths: long pairs leave long tails for the short ones that follow)."""

@@ -277,6 +277,11 @@ def test_filter_oracle_matches_reference_goldens(asm, oracle, name):
         key = f"g{g}_a{af}_x{x}o{o}e{e}"
         assert np.array_equal(ps, gold["af_pass_" + key]), (name, key, "check_pass")
         assert np.array_equal(ed, np.where(ps == 1, gold["af_ed_" + key], -1)), (name, key, "get_ED")
+    for g, af, x, o, e, st in FILTER_INDEX["affine_shd_settings"]:  # ... with init_affine's SHD_enable / SHD_threshold
+        ed, ps = oracle.simd_ed_affine(hb, g, af, x, o, e, shd_t=st)
+        key = f"g{g}_a{af}_x{x}o{o}e{e}_s{st}"
+        assert np.array_equal(ps, gold["afs_pass_" + key]), (name, key, "check_pass")
+        assert np.array_equal(ed, np.where(ps == 1, gold["afs_ed_" + key], -1)), (name, key, "get_ED")
 
 
 def test_filter_affine_hand_cases(asm, oracle):

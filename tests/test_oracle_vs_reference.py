@@ -149,3 +149,28 @@ def test_simd_ed_affine_clean_matches_the_compiled_reference(asm, oracle, settin
         r_ed, r_ps = ref.simd_ed_affine(hb, g, af, x, o, e)
         assert np.array_equal(o_ps, r_ps), setting
         assert np.array_equal(o_ed, np.where(r_ps == 1, r_ed, -1)), setting
+
+
+@pytest.mark.skipif(not oracle_binding.have_reference_simd(), reason="oracle/_ref/libasm_ref_simd.so not built")
+@pytest.mark.parametrize("setting", [(3, 60, 2, 3, 1, 3), (6, 30, 1, 1, 1, 6), (6, 30, 1, 1, 1, 2), (12, 120, 4, 6, 2, 5), (16, 90, 2, 3, 1, 16),
+                                     (20, 40, 1, 2, 1, 0), (5, 50, 2, 3, 1, 4)])
+def test_simd_ed_affine_with_shd_matches_the_compiled_reference(asm, oracle, setting):
+    """init_affine(..., SHD_enable = true, SHD_threshold): run_affine starts with the mask-array SHD over the FIRST
+    2*SHD_threshold+1 lane masks (SIMD_ED.cpp:489-492, SHD.cpp:334-372) — centred on the main lane only when SHD_threshold equals
+    the gap threshold.  Oracle against the compiled reference, centred and off-centre, thresholds that reject most and none."""
+    from tests.util import random_ragged_batch
+    ref = oracle_binding.load_reference_simd()
+    g, af, x, o, e, shd_t = setting
+    batches = [asm.generate_pairs(asm.workload(wl)[0], 29, n) for wl, n in (("C2", 2500), ("C3", 1200), ("C4", 2000), ("C5", 2000))]
+    batches.append(random_ragged_batch(asm, 6, 1500, 0, 300, err=0.15))
+    rejected = 0
+    for hb in batches:
+        o_ed, o_ps = oracle.simd_ed_affine(hb, g, af, x, o, e, shd_t=shd_t)
+        r_ed, r_ps = ref.simd_ed_affine(hb, g, af, x, o, e, shd_t=shd_t)
+        assert np.array_equal(o_ps, r_ps), setting
+        assert np.array_equal(o_ed, np.where(r_ps == 1, r_ed, -1)), setting
+        plain, _ = oracle.simd_ed_affine(hb, g, af, x, o, e)
+        assert ((o_ed == plain) | (o_ed == -1)).all()  # the filter only ever rejects
+        rejected += int(((o_ed == -1) & (plain != -1)).sum())
+    if shd_t <= 4:
+        assert rejected > 0, setting  # a tight threshold really filters

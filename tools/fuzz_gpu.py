@@ -60,6 +60,9 @@ while time.time() - t0 < budget:
         ax = int(rng.integers(1, 8)); ae = int(rng.integers(1, 5)); ao = ae + int(rng.integers(0, 6))
         want_a, _ = orc.simd_ed_affine(hb, g, af, ax, ao, ae)
         res.append(("simd_af", bool(np.array_equal(eng.simd_ed_affine(batch, g, af, ax, ao, ae), want_a))))
+        st = int(rng.integers(0, min(g, 16) + 1))  # init_affine's SHD_threshold, SHD_enable = true
+        want_s, _ = orc.simd_ed_affine(hb, g, af, ax, ao, ae, shd_t=st)
+        res.append(("simd_af_shd", bool(np.array_equal(eng.simd_ed_affine(batch, g, af, ax, ao, ae, shd_threshold=st), want_s))))
     ok = all(v for _, v in res)
     bad += 0 if ok else 1
     print(f"case {case:3d} {desc:22s} n={hb.n:5d} k={k:2d} pen=({x},{o},{e}) mode={mode} semi={int(semi)}: " + " ".join(f"{a}={'ok' if v else 'FAIL'}" for a, v in res), flush=True)
