@@ -27,6 +27,7 @@ ALIGNER_NAMES = {NW: "nw", LEAP: "leap", GREEDY: "greedy"}
 GREEDY_SEQUENTIAL, GREEDY_CLEAN = 0, 1
 FILTER_SEQUENTIAL, FILTER_CLEAN = 0, 1
 ALIGN_GLOBAL, ALIGN_SEMI_GLOBAL = 0, 1
+LEAP_GLOBAL, LEAP_LOCAL, LEAP_SEMI_FREE_BEGIN, LEAP_SEMI_FREE_END = 0, 1, 2, 3  # asm_params.leap_mode: LV::init's ED_modes
 GEN_EXACT_ERRORS, GEN_PER_BASE, GEN_UP_TO_ERRORS = 0, 1, 2
 GREEDY_MAX_LENGTH = 128
 LEAP_MAX_LENGTH = 256
@@ -45,13 +46,14 @@ class Params(ctypes.Structure):
 
     _fields_ = [("k", ctypes.c_int32), ("x", ctypes.c_int32), ("o", ctypes.c_int32), ("e", ctypes.c_int32),
                 ("p_match", ctypes.c_double), ("p_mismatch", ctypes.c_double), ("p_indel", ctypes.c_double),
-                ("alignment_type", ctypes.c_int32), ("reserved_", ctypes.c_int32)]
+                ("alignment_type", ctypes.c_int32), ("leap_mode", ctypes.c_int32)]
 
     @classmethod
     def default(cls, k: int = 3, x: int = 1, o: int = 1, e: int = 1, p_match: float = 0.80,
-                p_mismatch: float = 0.20 / 3, p_indel: float = 0.40 / 3, alignment_type: int = 0) -> "Params":
-        """alignment_type: ALIGN_GLOBAL (0) or ALIGN_SEMI_GLOBAL (1) — hurdle_matrix's alignment_type_t; Greedy only."""
-        return cls(k, x, o, e, p_match, p_mismatch, p_indel, alignment_type, 0)
+                p_mismatch: float = 0.20 / 3, p_indel: float = 0.40 / 3, alignment_type: int = 0, leap_mode: int = 0) -> "Params":
+        """alignment_type: ALIGN_GLOBAL (0) or ALIGN_SEMI_GLOBAL (1) — hurdle_matrix's alignment_type_t; Greedy only.
+        leap_mode: LEAP_GLOBAL (0, the harness) / LEAP_LOCAL / LEAP_SEMI_FREE_BEGIN / LEAP_SEMI_FREE_END — LV::init's ED_modes."""
+        return cls(k, x, o, e, p_match, p_mismatch, p_indel, alignment_type, leap_mode)
 
 
 class StreamStats(ctypes.Structure):

@@ -649,7 +649,7 @@ void asm_default_params(asm_params* p) {
     p->p_mismatch = 0.20 / 3;
     p->p_indel = 0.40 / 3;
     p->alignment_type = ASM_ALIGN_GLOBAL; /* hurdle_matrix.h:553 default; the harness never passes another */
-    p->reserved_ = 0;
+    p->leap_mode = ASM_LEAP_GLOBAL;
 }
 
 int asm_device_count(void) {
@@ -1385,6 +1385,10 @@ static int check_params(asm_handle* h, int aligner, const asm_params* p, int max
             return fail(h, ASM_EINVAL, "LEAP: need x >= 1, o >= e >= 1 (LV_BAG.cpp:165-166)");
         if (p->x > ASM_WIDE_MAX_PENALTY || p->o > ASM_WIDE_MAX_PENALTY)
             return fail(h, ASM_EUNSUPPORTED, "LEAP: penalties above the compiled history depth");
+        if (p->leap_mode < ASM_LEAP_GLOBAL || p->leap_mode > ASM_LEAP_SEMI_FREE_END)
+            return fail(h, ASM_EINVAL, "LEAP: leap_mode must be one of ASM_LEAP_GLOBAL/LOCAL/SEMI_FREE_BEGIN/SEMI_FREE_END");
+        if (p->leap_mode != ASM_LEAP_GLOBAL && maxlen > 512)
+            return fail(h, ASM_EUNSUPPORTED, "LEAP: the non-GLOBAL modes are built for strings up to 512 characters");
     } else if (aligner == ASM_NW) {
         /* nw_affine_kernel keeps H/E/F below NW_BIG (int16 halves of one dword at the block boundary): every cell is at most
          * gap(i) + gap(j), and E/F one gap-open above that */
@@ -1449,7 +1453,11 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
                 break;
         }
     } else if (aligner == ASM_LEAP) {
-        if (unit && p->k >= 1 && p->k <= 5 && b.maxlen <= 384) {
+        if (p->leap_mode != ASM_LEAP_GLOBAL) {
+            /* LV's other ED_modes have no caller in the reference: one kernel serves them, the workgroup-per-pair form that takes
+             * any band and any penalties (asm_wide.h) */
+            launch_leap_wide(h->stream, planes, lens, b.n, b.w4, p->k, p->x, p->o, p->e, out, (int)p->leap_mode);
+        } else if (unit && p->k >= 1 && p->k <= 5 && b.maxlen <= 384) {
             switch (p->k) {
                 case 1: HIPCHK(h, launch_leap_unit<1>(h, b, out, hint)); break;
                 case 2: HIPCHK(h, launch_leap_unit<2>(h, b, out, hint)); break;

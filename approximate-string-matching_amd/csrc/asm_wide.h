@@ -23,7 +23,10 @@ template <int W64>
 __global__ __launch_bounds__(ASM_WIDE_THREADS) void leap_wide_kernel(const uint4* __restrict__ planes,
                                                                      const uint32_t* __restrict__ lens, long n,
                                                                      int w4, int k, int x, int o, int ext,
-                                                                     OutMap out) {
+                                                                     int mode /* ASM_LEAP_* (LV::init's ED_modes) */, OutMap out) {
+    // LOCAL and SEMI_FREE_BEGIN give every lane a start at generation 0, at the lane's distance from the main one (LV_BAG.cpp:
+    // 102-104); LOCAL and SEMI_FREE_END accept any lane that reaches the end, without converge_ED's lane term and threshold (:220-238)
+    const bool all_start = mode == 1 || mode == 2, converge_rule = mode == 0 || mode == 2;
     __shared__ int s_end[ASM_WIDE_RING][ASM_WIDE_THREADS + 2];
     __shared__ int s_ip[ASM_WIDE_RING][ASM_WIDE_THREADS + 2];
     __shared__ int s_dp[ASM_WIDE_RING][ASM_WIDE_THREADS + 2];
@@ -55,9 +58,11 @@ __global__ __launch_bounds__(ASM_WIDE_THREADS) void leap_wide_kernel(const uint4
             }
         }
         int pass0 = 0;
-        if (active && d == 0) { /* e = 0, LV_BAG.cpp:131-147 */
-            int e0 = vw_next_one<W64>(mask, 0);
-            e0 = e0 > len ? len : e0;
+        if (active && (d == 0 || all_start)) { /* e = 0, LV_BAG.cpp:131-147: start[l][0] = |l - mid| */
+            const int from0 = diff > len ? len : diff; /* as a start of any later generation (count_ID_length, :9-23) */
+            int r0 = vw_next_one<W64>(mask, from0);
+            r0 = r0 > len ? len : r0;
+            const int e0 = diff > len ? diff : r0;
             s_end[0][t + 1] = e0;
             pass0 = (e0 == len);
         }
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(ASM_WIDE_THREADS) void leap_wide_kernel(const uint4
                         enew = st > len ? st : r;
                         if (enew == len) {
                             const int conv = e + (diff ? o + (diff - 1) * ext : 0);
-                            if (conv <= ASM_LEAP_AF_THRESHOLD) pass = 1;
+                            if (!converge_rule || conv <= ASM_LEAP_AF_THRESHOLD) pass = 1;
                         }
                     }
                 }
@@ -114,18 +119,18 @@ __global__ __launch_bounds__(ASM_WIDE_THREADS) void leap_wide_kernel(const uint4
 }
 
 static inline void launch_leap_wide(hipStream_t stream, const uint4* planes, const uint32_t* lens, int64_t n, int w4,
-                                    int k, int x, int o, int e, OutMap out) {
+                                    int k, int x, int o, int e, OutMap out, int mode = 0) {
     int64_t blocks = n < 256 * 32 ? n : 256 * 32;
     const int maxw = w4 * 2;
     if (maxw <= 2)
         hipLaunchKernelGGL(leap_wide_kernel<2>, dim3((unsigned)blocks), dim3(ASM_WIDE_THREADS), 0, stream, planes, lens,
-                           (long)n, w4, k, x, o, e, out);
+                           (long)n, w4, k, x, o, e, mode, out);
     else if (maxw <= 4)
         hipLaunchKernelGGL(leap_wide_kernel<4>, dim3((unsigned)blocks), dim3(ASM_WIDE_THREADS), 0, stream, planes, lens,
-                           (long)n, w4, k, x, o, e, out);
+                           (long)n, w4, k, x, o, e, mode, out);
     else
         hipLaunchKernelGGL(leap_wide_kernel<8>, dim3((unsigned)blocks), dim3(ASM_WIDE_THREADS), 0, stream, planes, lens,
-                           (long)n, w4, k, x, o, e, out);
+                           (long)n, w4, k, x, o, e, mode, out);
 }
 
 // --------------------------------------------------------------------------------------------------------

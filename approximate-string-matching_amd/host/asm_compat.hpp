@@ -135,9 +135,12 @@ class LV {
 public:
     LV() { asm_default_params(&p_); }
     void init(int gap_threshold, int af_threshold, ED_modes mode, int ms_penalty, int gap_open_penalty, int gap_ext_penalty) {
-        if (mode != ED_GLOBAL || af_threshold != ASM_LEAP_AF_THRESHOLD)
-            throw std::runtime_error("LV::init: the accelerated path is ED_GLOBAL with af_threshold 200 (benchmark_utils.h:289)");
+        if (af_threshold != ASM_LEAP_AF_THRESHOLD)
+            throw std::runtime_error("LV::init: the accelerated path has af_threshold 200 (benchmark_utils.h:289)");
         p_.k = gap_threshold, p_.x = ms_penalty, p_.o = gap_open_penalty, p_.e = gap_ext_penalty;
+        p_.leap_mode = mode == ED_GLOBAL ? ASM_LEAP_GLOBAL  // LV_BAG.h:38 -> asm_params.leap_mode
+                       : mode == ED_LOCAL ? ASM_LEAP_LOCAL
+                       : mode == ED_SEMI_FREE_BEGIN ? ASM_LEAP_SEMI_FREE_BEGIN : ASM_LEAP_SEMI_FREE_END;
     }
     void load_reads(char* read, char* ref, int length) {  // NUL-terminated inputs, as the harness passes them
         read_.assign(read, strnlen(read, (size_t)length));

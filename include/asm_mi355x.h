@@ -67,10 +67,18 @@ typedef struct asm_params {
     int32_t alignment_type; /* Greedy: ASM_ALIGN_GLOBAL (default, what the harness uses) or ASM_ALIGN_SEMI_GLOBAL —
                                hurdle_matrix's alignment_type_t (hurdle_matrix.h:477,553; utils.h:554-558); LOCAL is
                                declared but unsupported in the reference (hurdle_matrix.h:467).  NW and LEAP ignore it. */
-    int32_t reserved_;
+    int32_t leap_mode;      /* LEAP: LV::init's ED_modes (LEAP_SIMD/LV_BAG.h:38,65) — ASM_LEAP_GLOBAL (default; what the harness
+                               passes, benchmark_utils.h:289), ASM_LEAP_LOCAL, ASM_LEAP_SEMI_FREE_BEGIN, ASM_LEAP_SEMI_FREE_END:
+                               LOCAL and SEMI_FREE_BEGIN start every lane at generation 0 (LV_BAG.cpp:102-104), LOCAL and
+                               SEMI_FREE_END accept any lane that reaches the end (:220-238).  NW and Greedy ignore it.  (This
+                               field was `reserved_`, always 0 = GLOBAL.) */
 } asm_params;
 #define ASM_ALIGN_GLOBAL 0
 #define ASM_ALIGN_SEMI_GLOBAL 1
+#define ASM_LEAP_GLOBAL 0
+#define ASM_LEAP_LOCAL 1
+#define ASM_LEAP_SEMI_FREE_BEGIN 2
+#define ASM_LEAP_SEMI_FREE_END 3
 
 /* ---- library / handle ------------------------------------------------------------------------------ */
 const char* asm_version(void);

@@ -411,15 +411,25 @@ static inline int leap_extend(const char* a, int m, const char* b, int n, int le
     return pos;
 }
 
-static int leap_pair(leap_tab* t, const char* a, int m, const char* b, int n, int k, int x, int o, int ext) {
+/* mode: ORC_LEAP_GLOBAL (what the harness uses), ORC_LEAP_LOCAL, ORC_LEAP_SEMI_FREE_BEGIN, ORC_LEAP_SEMI_FREE_END — LV::init's
+ * ED_modes (LV_BAG.h:38).  They differ in two places: LOCAL and SEMI_FREE_BEGIN give EVERY lane a start at generation 0, at
+ * the lane's distance from the main one (LV_BAG.cpp:102-104); LOCAL and SEMI_FREE_END accept any lane that reaches the end,
+ * without the lane-distance term and the affine threshold of converge_ED (:220-238). */
+static int leap_pair(leap_tab* t, const char* a, int m, const char* b, int n, int k, int x, int o, int ext, int mode) {
     int len = m > n ? m : n; /* benchmark_utils.h:162 */
     int mid = k + 1, lanes = t->lanes;
     int used_e = 0, result = -1;
-    T(t->start, mid, 0) = 0; /* LV_BAG.cpp:102-104, ED_GLOBAL */
-    T(t->end, mid, 0) = leap_extend(a, m, b, n, len, mid, mid, 0); /* LV_BAG.cpp:131-147 */
-    if (T(t->end, mid, 0) == len) {
-        result = 0;
-        goto done;
+    const int all_start = mode == ORC_LEAP_LOCAL || mode == ORC_LEAP_SEMI_FREE_BEGIN;
+    const int converge_rule = mode == ORC_LEAP_GLOBAL || mode == ORC_LEAP_SEMI_FREE_BEGIN;
+    for (int l = 1; l < lanes - 1; l++) { /* LV_BAG.cpp:102-104 (init) and :131-147 (generation 0), lanes in ascending order */
+        const int dist = abs(l - mid);
+        if (dist != 0 && !all_start) continue;
+        T(t->start, l, 0) = dist;
+        T(t->end, l, 0) = leap_extend(a, m, b, n, len, mid, l, dist);
+        if (T(t->end, l, 0) == len) {
+            result = 0;
+            goto done;
+        }
     }
     {
         int converge = 1000000, pass = 0; /* LV_BAG.cpp:122-125 */
@@ -447,7 +457,9 @@ static int leap_pair(leap_tab* t, const char* a, int m, const char* b, int n, in
                     if (en2 == len) { /* LV_BAG.cpp:220-238 */
                         int diff = abs(mid - l);
                         int conv = e + (diff ? o + (diff - 1) * ext : 0);
-                        if (conv <= LEAP_AF && conv < converge) {
+                        if (!converge_rule) {
+                            result = e, pass = 1; /* :233-237 */
+                        } else if (conv <= LEAP_AF && conv < converge) {
                             result = e; /* final_ED, NOT converge_ED (LV_BAG.cpp:228,356-358) */
                             pass = 1;
                             converge = conv;
@@ -466,7 +478,13 @@ done:
 
 int orc_leap_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
                    const uint32_t* ref_off, int k, int x, int o, int e, int32_t* eds) {
+    return orc_leap_mode_batch(n, reads, read_off, refs, ref_off, k, x, o, e, ORC_LEAP_GLOBAL, eds);
+}
+
+int orc_leap_mode_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
+                        const uint32_t* ref_off, int k, int x, int o, int e, int mode, int32_t* eds) {
     if (k < 0 || x < 1 || o < 1 || e < 1 || o < e) return -1; /* L4: reference assumes o >= ext; positive penalties */
+    if (mode < ORC_LEAP_GLOBAL || mode > ORC_LEAP_SEMI_FREE_END) return -1;
     int rc = 0;
 #pragma omp parallel num_threads(g_threads)
     {
@@ -478,7 +496,7 @@ int orc_leap_batch(int64_t n, const char* reads, const uint32_t* read_off, const
 #pragma omp for schedule(static)
             for (int64_t i = 0; i < n; i++) {
                 int m = (int)(read_off[i + 1] - read_off[i]), nn = (int)(ref_off[i + 1] - ref_off[i]);
-                eds[i] = leap_pair(&t, reads + read_off[i], m, refs + ref_off[i], nn, k, x, o, e);
+                eds[i] = leap_pair(&t, reads + read_off[i], m, refs + ref_off[i], nn, k, x, o, e, mode);
             }
             free(t.start);
         }

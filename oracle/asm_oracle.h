@@ -62,6 +62,14 @@ void orc_greedy_get_final_buffers(uint8_t* ab /* [256] */);
  * eds[i] = -1 when no lane passes within af_threshold=200 (reference returns a stale value there). */
 int orc_leap_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
                    const uint32_t* ref_off, int k, int x, int o, int e, int32_t* eds);
+/* LV::init's ED_modes (LV_BAG.h:38; own numbering, GLOBAL = 0 = what the harness uses): which lanes start at generation 0 and
+ * whether reaching the end is judged by converge_ED (LV_BAG.cpp:102-104,220-238) */
+#define ORC_LEAP_GLOBAL 0
+#define ORC_LEAP_LOCAL 1
+#define ORC_LEAP_SEMI_FREE_BEGIN 2
+#define ORC_LEAP_SEMI_FREE_END 3
+int orc_leap_mode_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
+                        const uint32_t* ref_off, int k, int x, int o, int e, int mode, int32_t* eds);
 
 /* NW: global affine-gap distance, match 0, mismatch x, gap(L) = o + (L-1)*e.
  * Semantics of the call site GASMA/benchmark/benchmark_utils.h:139-142,288 (parasail, absent): penalty = -score. */

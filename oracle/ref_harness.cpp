@@ -94,6 +94,32 @@ int ref_greedy_batch(int64_t n, const char* reads, const uint32_t* read_off, con
                                   cigars, cigar_stride, views);
 }
 
+// LV with any of its ED_modes (LV_BAG.h:38); mode in the oracle's numbering (0 GLOBAL, 1 LOCAL, 2 SEMI_FREE_BEGIN, 3 SEMI_FREE_END).
+// clean = 1: init() before every pair (fresh tables); clean = 0: one init, reset() between pairs, as the harness drives it —
+// reset() leaves the I/D/end tables of the pair before in place (LV_BAG.cpp:121-125).
+int ref_leap_mode_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off, int k,
+                        int x, int o, int e, int mode, int clean, int32_t* eds) {
+    static const ED_modes map[4] = {ED_GLOBAL, ED_LOCAL, ED_SEMI_FREE_BEGIN, ED_SEMI_FREE_END};
+    if (mode < 0 || mode > 3) return -1;
+    LV* lv = new LV;
+    lv->init(k, 200, map[mode], x, o, e);
+    std::string s1, s2;
+    for (int64_t i = 0; i < n; i++) {
+        int m = (int)(read_off[i + 1] - read_off[i]);
+        int nn = (int)(ref_off[i + 1] - ref_off[i]);
+        s1.assign(reads + read_off[i], m);
+        s2.assign(refs + ref_off[i], nn);
+        int length = m > nn ? m : nn;
+        if (clean && i > 0) lv->init(k, 200, map[mode], x, o, e);
+        lv->load_reads((char*)s1.c_str(), (char*)s2.c_str(), length);
+        lv->reset();
+        lv->run();
+        eds[i] = lv->check_pass() ? lv->get_ED() : -1;
+    }
+    delete lv;
+    return 0;
+}
+
 // full = 1 additionally runs backtrack() and get_CIGAR() as the harness's timed region does (benchmark_utils.h:170-174)
 int ref_leap_batch_ex(int64_t n, const char* reads, const uint32_t* read_off, const char* refs,
                       const uint32_t* ref_off, int k, int x, int o, int e, int32_t* eds, uint8_t* pass, int full) {

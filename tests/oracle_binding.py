@@ -68,6 +68,7 @@ class Oracle:
         lib.orc_greedy_batch_typed.argtypes = b5 + [_i] * 4 + [_vp, _i, _i, _vp, _vp, _i, _vp]
         lib.orc_greedy_views.argtypes = b5 + [_i, _vp]
         lib.orc_leap_batch.argtypes = b5 + [_i] * 4 + [_vp]
+        lib.orc_leap_mode_batch.argtypes = b5 + [_i] * 5 + [_vp]
         lib.orc_nw_batch.argtypes = b5 + [_i] * 3 + [_vp]
         lib.orc_levenshtein_batch.argtypes = b5 + [_vp]
         lib.orc_nw_cigar_batch.argtypes = b5 + [_i] * 3 + [_vp, _vp, _i]
@@ -161,10 +162,11 @@ class Oracle:
         assert self.lib.orc_greedy_views(*args, mode, views.ctypes.data) == 0
         return views[:hb.n * 256].reshape(hb.n, 2, 128)
 
-    def leap(self, hb, k=3, x=1, o=1, e=1):
+    def leap(self, hb, k=3, x=1, o=1, e=1, mode=0):
+        """mode: LV::init's ED_modes in the oracle's numbering — 0 GLOBAL (the harness), 1 LOCAL, 2 SEMI_FREE_BEGIN, 3 SEMI_FREE_END."""
         keep, args = _batch_args(hb)
         eds = np.zeros(hb.n, np.int32)
-        rc = self.lib.orc_leap_batch(*args, k, x, o, e, eds.ctypes.data)
+        rc = self.lib.orc_leap_mode_batch(*args, k, x, o, e, mode, eds.ctypes.data)
         assert rc == 0, rc
         return eds
 
@@ -279,6 +281,7 @@ class Reference:
         lib.ref_greedy_batch_typed.argtypes = b5 + [_i] * 4 + [ctypes.c_double] * 3 + [_i, _i, _vp, _vp, _i, _vp]
         lib.ref_leap_batch.argtypes = b5 + [_i] * 4 + [_vp, _vp]
         lib.ref_leap_batch_ex.argtypes = b5 + [_i] * 4 + [_vp, _vp, _i]
+        lib.ref_leap_mode_batch.argtypes = b5 + [_i] * 6 + [_vp]
         lib.ref_convert2bit1.argtypes = [_vp, _vp, _vp]
 
     def greedy(self, hb, k=3, x=1, o=1, e=1, probs=DEFAULT_PROBS, mode=1, cigars=False, views=False, semi=False):
@@ -302,6 +305,13 @@ class Reference:
         keep, args = _batch_args(hb)
         eds = np.zeros(hb.n, np.int32)
         assert self.lib.ref_leap_batch_ex(*args, k, x, o, e, eds.ctypes.data, None, 1 if full else 0) == 0
+        return eds
+
+    def leap_mode(self, hb, k=3, x=1, o=1, e=1, mode=0, clean=True):
+        """LV with ED_modes `mode` (oracle numbering); clean: init() before every pair, else one object with reset() as the harness."""
+        keep, args = _batch_args(hb)
+        eds = np.zeros(hb.n, np.int32)
+        assert self.lib.ref_leap_mode_batch(*args, k, x, o, e, mode, 1 if clean else 0, eds.ctypes.data) == 0
         return eds
 
     def convert2bit1(self, buf128):

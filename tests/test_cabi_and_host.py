@@ -23,12 +23,12 @@ def test_library_exports_every_declared_symbol(asm):
 
 
 def test_struct_layouts_match_header(asm):
-    assert ctypes.sizeof(asm.Params) == 48 and asm.Params.p_match.offset == 16 and asm.Params.alignment_type.offset == 40
+    assert ctypes.sizeof(asm.Params) == 48 and asm.Params.p_match.offset == 16 and asm.Params.alignment_type.offset == 40 and asm.Params.leap_mode.offset == 44
     assert ctypes.sizeof(asm.GenConfig) == 40 and asm.GenConfig.err.offset == 20
     p = asm.Params()
     asm.load_library().asm_default_params(ctypes.byref(p))
     assert (p.k, p.x, p.o, p.e) == (3, 1, 1, 1) and abs(p.p_match - 0.8) < 1e-12 and abs(p.p_indel - 0.4 / 3) < 1e-12
-    assert p.alignment_type == asm.ALIGN_GLOBAL
+    assert p.alignment_type == asm.ALIGN_GLOBAL and p.leap_mode == asm.LEAP_GLOBAL
 
 
 def test_no_gpu_means_loud_failure_not_fallback(asm):

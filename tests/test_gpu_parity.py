@@ -583,6 +583,26 @@ def test_simd_ed_affine_filter_with_shd_matches_oracle(asm, engine, oracle, wl, 
             engine.simd_ed_affine(batch, g, af, x, o, e, shd_threshold=bad_t)
 
 
+@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("wl,n", [("C2", 6000), ("C5", 4000), ("C3", 1500)])
+def test_leap_ed_modes(asm, engine, oracle, wl, n, mode):
+    """asm_params.leap_mode = LV::init's ED_modes LOCAL / SEMI_FREE_BEGIN / SEMI_FREE_END (no caller in the reference; one
+    kernel serves them): narrow and wide bands, unit and general penalties, mixed lengths; and the argument check."""
+    cfg, _, _ = asm.workload(wl)
+    hb = asm.generate_pairs(cfg, 53, n)
+    batch = engine.upload(hb, asm.GREEDY_CLEAN)
+    ok = np.maximum(*hb.lengths()) <= 256
+    for k, x, o, e in ((3, 1, 1, 1), (5, 2, 3, 1), (12, 1, 1, 1), (8, 4, 6, 2), (30, 1, 2, 1)):
+        want = oracle.leap(hb, k, x, o, e, mode)
+        got = engine.align(batch, asm.LEAP, asm.Params.default(k=k, x=x, o=o, e=e, leap_mode=mode))
+        bad = np.nonzero((got != want) & ok)[0]
+        assert bad.size == 0, (wl, mode, k, x, o, e, bad[:5], got[bad[:5]], want[bad[:5]])
+    with pytest.raises(asm.AsmError):
+        engine.align(batch, asm.LEAP, asm.Params.default(k=3, leap_mode=4))
+    # GLOBAL is untouched by the field's new meaning
+    assert np.array_equal(engine.align(batch, asm.LEAP, asm.Params.default(k=3, leap_mode=asm.LEAP_GLOBAL))[ok], oracle.leap(hb, 3)[ok])
+
+
 def test_filters_ignore_the_stale_tails_of_sequential_batches(asm, engine, oracle):
     """A batch packed for Greedy's sequential mode keeps the reference's stale buffer tails beyond each string's end; NW, LEAP
     and the three filters must not see them (mixed lengths: long pairs leave long tails for the short ones that follow)."""

@@ -174,3 +174,25 @@ def test_simd_ed_affine_with_shd_matches_the_compiled_reference(asm, oracle, set
         rejected += int(((o_ed == -1) & (plain != -1)).sum())
     if shd_t <= 4:
         assert rejected > 0, setting  # a tight threshold really filters
+
+
+@pytest.mark.skipif(not oracle_binding.have_reference(), reason="oracle/_ref/libasm_ref.so not built")
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_leap_ed_modes_match_the_compiled_reference(asm, oracle, mode):
+    """LV::init's other ED_modes (LOCAL, SEMI_FREE_BEGIN, SEMI_FREE_END; LV_BAG.h:38, LV_BAG.cpp:102-104,220-238): the oracle
+    against the compiled reference, driven both ways — init() before every pair and one object with reset() as the harness does
+    (the tables reset() leaves behind change nothing on these inputs either) — narrow and wide bands, three penalty sets."""
+    from tests.util import random_ragged_batch
+    ref = oracle_binding.load_reference()
+    batches = [asm.generate_pairs(asm.workload(wl)[0], 37, n) for wl, n in (("C2", 2500), ("C3", 600), ("C4", 2000), ("C5", 1500))]
+    batches.append(random_ragged_batch(asm, 7, 1200, 0, 250, err=0.15))
+    differs_from_global = 0
+    for hb in batches:
+        ok = np.maximum(*hb.lengths()) <= 256  # LEAP beyond 256 bases is undefined in the reference (SURVEY L7)
+        for k, x, o, e in ((3, 1, 1, 1), (5, 2, 3, 1), (10, 1, 1, 1), (8, 4, 6, 2), (30, 1, 1, 1)):
+            got = oracle.leap(hb, k, x, o, e, mode)
+            assert np.array_equal(got[ok], ref.leap_mode(hb, k, x, o, e, mode, clean=True)[ok]), (mode, k, x, o, e)
+            assert np.array_equal(got[ok], ref.leap_mode(hb, k, x, o, e, mode, clean=False)[ok]), (mode, k, x, o, e, "as run")
+            differs_from_global += int((got[ok] != oracle.leap(hb, k, x, o, e)[ok]).sum())
+    if mode in (1, 2):
+        assert differs_from_global > 0  # free begin gaps really change results

@@ -41,6 +41,10 @@ while time.time() - t0 < budget:
     res = []
     got = eng.align(batch, m.NW, p); res.append(("nw", bool(np.array_equal(got, orc.nw(hb, x, o, e)))))
     got = eng.align(batch, m.LEAP, p); res.append(("leap", bool(np.array_equal(got[ld], orc.leap(hb, k, x, o, e)[ld]))))
+    if case % 4 == 0 and int(np.maximum(*hb.lengths()).max(initial=0)) <= 512:  # LV's other ED_modes (one in four cases: the generic kernel is slow)
+        lm = int(rng.integers(1, 4))
+        pm = m.Params.default(k=k, x=x, o=o, e=e, leap_mode=lm)
+        got = eng.align(batch, m.LEAP, pm); res.append((f"leap_m{lm}", bool(np.array_equal(got[ld], orc.leap(hb, k, x, o, e, lm)[ld]))))
     want, wcig = orc.greedy(hb, k, x, o, e, mode=mode, cigars=True, semi=semi)
     cost, cig, nops = eng.greedy_with_cigar(batch, p, cap=255)
     res.append(("greedy", bool(np.array_equal(cost[gd], want[gd]))))
