@@ -158,6 +158,7 @@ def load_library() -> ctypes.CDLL:
         "asm_simd_ed_batch_async": (i32, [vp, vp, i32, i32, i32, vp, vp]),
         "asm_simd_ed_affine_batch_async": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
         "asm_simd_ed_affine_shd_batch_async": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+        "asm_simd_ed_affine_mode_batch_async": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
         "asm_shd_filter_batch_async": (i32, [vp, vp, i32, vp]),
         "asm_pipeline_join_async": (i32, [vp]),
         "asm_profile_enable": (i32, [vp, i32, c.c_uint32]),
@@ -494,11 +495,15 @@ class Engine:
             self.free(d_out)
 
     def simd_ed_affine_async(self, batch: DeviceBatch, gap_threshold: int, af_threshold: int, x: int, o: int, e: int, d_ed: int,
-                             shd_threshold: Optional[int] = None) -> None:
+                             shd_threshold: Optional[int] = None, mode: int = 0) -> None:
         """SIMD_ED::init_affine(gap_threshold, af_threshold, ED_GLOBAL, x, o, e[, true, shd_threshold]) + load_reads/calculate_masks/
         reset/run per pair, every pair from clean tables: d_ed[i] = get_ED() when check_pass() (1000000 for a pair exact at e = 0)
         else -1.  shd_threshold: init_affine's SHD_enable = true with that SHD_threshold (None: off, the reference's default)."""
-        if shd_threshold is None:
+        if mode != 0:  # init_affine's ED_modes (LEAP_LOCAL / LEAP_SEMI_FREE_BEGIN / LEAP_SEMI_FREE_END)
+            self._chk(self.lib.asm_simd_ed_affine_mode_batch_async(self.h, batch.ptr, int(gap_threshold), int(af_threshold), int(x),
+                                                                   int(o), int(e), -1 if shd_threshold is None else int(shd_threshold),
+                                                                   int(mode), d_ed))
+        elif shd_threshold is None:
             self._chk(self.lib.asm_simd_ed_affine_batch_async(self.h, batch.ptr, int(gap_threshold), int(af_threshold), int(x), int(o),
                                                               int(e), d_ed))
         else:
@@ -506,10 +511,10 @@ class Engine:
                                                                   int(o), int(e), int(shd_threshold), d_ed))
 
     def simd_ed_affine(self, batch: DeviceBatch, gap_threshold: int, af_threshold: int, x: int, o: int, e: int,
-                       shd_threshold: Optional[int] = None) -> np.ndarray:
+                       shd_threshold: Optional[int] = None, mode: int = 0) -> np.ndarray:
         d_out = self.malloc(4 * max(batch.n, 1))
         try:
-            self.simd_ed_affine_async(batch, gap_threshold, af_threshold, x, o, e, d_out, shd_threshold)
+            self.simd_ed_affine_async(batch, gap_threshold, af_threshold, x, o, e, d_out, shd_threshold, mode)
             return self.to_host(d_out, batch.n)
         finally:
             self.free(d_out)

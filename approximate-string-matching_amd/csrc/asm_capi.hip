@@ -1797,9 +1797,17 @@ int asm_simd_ed_batch_async(asm_handle* h, const asm_batch* b, int ed_threshold,
     return rc;
 }
 
+static int simd_ed_affine_launch(asm_handle* h, const asm_batch* b, int gap_threshold, int af_threshold, int x, int o, int e, int mode,
+                                 int32_t* d_ed);
 int asm_simd_ed_affine_batch_async(asm_handle* h, const asm_batch* b, int gap_threshold, int af_threshold, int x, int o, int e,
                                    int32_t* d_ed) {
+    return simd_ed_affine_launch(h, b, gap_threshold, af_threshold, x, o, e, ASM_LEAP_GLOBAL, d_ed);
+}
+static int simd_ed_affine_launch(asm_handle* h, const asm_batch* b, int gap_threshold, int af_threshold, int x, int o, int e, int mode,
+                                 int32_t* d_ed) {
     if (!h || !b || !d_ed) return fail(h, ASM_EINVAL, "asm_simd_ed_affine_batch_async: NULL argument");
+    if (mode < ASM_LEAP_GLOBAL || mode > ASM_LEAP_SEMI_FREE_END)
+        return fail(h, ASM_EINVAL, "asm_simd_ed_affine_mode_batch_async: mode must be one of ASM_LEAP_GLOBAL/LOCAL/SEMI_FREE_BEGIN/SEMI_FREE_END");
     if (gap_threshold < 1 || gap_threshold > ASM_FILTER_MAX_T)
         return fail(h, ASM_EINVAL, "asm_simd_ed_affine_batch_async: gap threshold must be in [1, 32]");
     if (af_threshold < 1 || af_threshold > 512)
@@ -1823,19 +1831,19 @@ int asm_simd_ed_affine_batch_async(asm_handle* h, const asm_batch* b, int gap_th
         if (k.maxlen <= 128 && gap_threshold >= h->simd_quad_min) { /* four threads per pair */
             const size_t qlds = simd_quad_lds(gap_threshold, rg.gm, rg.gi);
             hipLaunchKernelGGL(simd_ed_affine_quad_kernel, dim3((unsigned)((k.n + 15) / 16)), dim3(64), qlds, h->stream, k.planes, k.lens,
-                               (long)k.n, k.w4, gap_threshold, af_threshold, x, o, e, rg.gm, rg.gi, out);
+                               (long)k.n, k.w4, gap_threshold, af_threshold, x, o, e, rg.gm, rg.gi, mode, out);
         } else if (k.maxlen <= 128) {
             if (lds > 64 * 1024)
                 HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&simd_ed_affine_kernel<2>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(simd_ed_affine_kernel<2>, grid, block, lds, h->stream, k.planes, k.lens, (long)k.n, k.w4, gap_threshold,
-                               af_threshold, x, o, e, rg.gm, rg.gi, out);
+                               af_threshold, x, o, e, rg.gm, rg.gi, mode, out);
         } else {
             if (lds > 64 * 1024)
                 HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&simd_ed_affine_kernel<4>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(simd_ed_affine_kernel<4>, grid, block, lds, h->stream, k.planes, k.lens, (long)k.n, k.w4, gap_threshold,
-                               af_threshold, x, o, e, rg.gm, rg.gi, out);
+                               af_threshold, x, o, e, rg.gm, rg.gi, mode, out);
         }
         HIPCHK(h, hipGetLastError());
     }
@@ -1844,10 +1852,17 @@ int asm_simd_ed_affine_batch_async(asm_handle* h, const asm_batch* b, int gap_th
 
 int asm_simd_ed_affine_shd_batch_async(asm_handle* h, const asm_batch* b, int gap_threshold, int af_threshold, int x, int o, int e,
                                        int shd_threshold, int32_t* d_ed) {
-    if (shd_threshold < 0 || shd_threshold > ASM_SHD_MAX_ERROR || shd_threshold > gap_threshold)
+    if (shd_threshold < 0) return fail(h, ASM_EINVAL, "asm_simd_ed_affine_shd_batch_async: SHD threshold must be in [0, min(16, gap threshold)]");
+    return asm_simd_ed_affine_mode_batch_async(h, b, gap_threshold, af_threshold, x, o, e, shd_threshold, ASM_LEAP_GLOBAL, d_ed);
+}
+
+int asm_simd_ed_affine_mode_batch_async(asm_handle* h, const asm_batch* b, int gap_threshold, int af_threshold, int x, int o, int e,
+                                        int shd_threshold, int mode, int32_t* d_ed) {
+    if (shd_threshold < 0) return simd_ed_affine_launch(h, b, gap_threshold, af_threshold, x, o, e, mode, d_ed); /* SHD off */
+    if (shd_threshold > ASM_SHD_MAX_ERROR || shd_threshold > gap_threshold)
         return fail(h, ASM_EINVAL, "asm_simd_ed_affine_shd_batch_async: SHD threshold must be in [0, min(16, gap threshold)] "
                                    "(the reference reads 2*SHD_threshold+1 of its 2*gap_threshold+1 lane masks)");
-    const int rc = asm_simd_ed_affine_batch_async(h, b, gap_threshold, af_threshold, x, o, e, d_ed);
+    const int rc = simd_ed_affine_launch(h, b, gap_threshold, af_threshold, x, o, e, mode, d_ed);
     if (rc != ASM_OK || b->n == 0) return rc;
     for (int q = 0; q < b->nb; q++) {
         const asm_bucket& k = b->bk[q];

@@ -222,7 +222,10 @@ __global__ __launch_bounds__(SIMD_ED_THREADS) void simd_ed_kernel(const uint4* _
 template <int W64>
 __global__ __launch_bounds__(64) void simd_ed_affine_kernel(const uint4* __restrict__ planes, const uint32_t* __restrict__ lens,
                                                             long n, int w4, int T, int af_t, int x, int o, int ext, int gm, int gi,
-                                                            OutMap out) {
+                                                            int mode /* ASM_LEAP_*: init_affine's ED_modes */, OutMap out) {
+    // LOCAL (1) and SEMI_FREE_BEGIN (2): every lane starts at generation 0, at its distance from the main lane (SIMD_ED.cpp:476-478,
+    // 497-516); LOCAL and SEMI_FREE_END (3): any lane that reaches the end passes and get_ED() is final_ED (:589-610,748-753)
+    const bool all_start = mode == 1 || mode == 2, converge_rule = mode == 0 || mode == 2;
     extern __shared__ uint16_t s_afring[]; /* `end` [gm][rows][TH], I [gi][rows][TH], D [gi][rows][TH] */
     const int TH = (int)blockDim.x, t = threadIdx.x;
     const int rows = 2 * T + 3, mid = T + 1; /* lanes 1 .. 2T+1, guard rows 0 and 2T+2 (SIMD_ED.cpp:452-453) */
@@ -249,16 +252,20 @@ __global__ __launch_bounds__(64) void simd_ed_affine_kernel(const uint4* __restr
         for (int q = 0; q < W64; q++) A0.w[q] &= lm.w[q], A1.w[q] &= lm.w[q], B0.w[q] &= lb.w[q], B1.w[q] &= lb.w[q];
     }
     int result = -2; /* -2: still running */
-    {   /* e = 0: only the main lane has a start (ED_GLOBAL, :474-477,497-516) */
-        const int e0 = simd_extend<W64>(simd_lane_mask<W64>(A0, A1, B0, B1, 0), 0, len);
-        r_en[mid * TH] = (uint16_t)(e0 + 2);
-        if (e0 == len) result = 1000000;
+    {   /* e = 0: the main lane (ED_GLOBAL, SEMI_FREE_END) or every lane at its distance (:474-477,497-516) */
+        const int l0 = all_start ? 1 : mid, l1 = all_start ? 2 * T + 1 : mid;
+        for (int l = l0; l <= l1; l++) {
+            const int dist = l < mid ? mid - l : l - mid;
+            const int e0 = simd_extend<W64>(simd_lane_mask<W64>(A0, A1, B0, B1, l - mid), dist, len);
+            r_en[l * TH] = (uint16_t)(e0 + 2);
+            if (e0 == len) result = converge_rule ? 1000000 : 0; /* converge_ED is never written here; final_ED = 0 */
+        }
     }
     for (int e = 1; e <= af_t; e++) {
         if (__ballot(result == -2) == 0ull) break;
         if (result != -2) continue;
         int dmax = e < o ? 0 : (e - o) / ext + 1; /* lanes a gap of this cost can have reached */
-        dmax = dmax > T ? T : dmax;
+        dmax = (dmax > T || all_start) ? T : dmax; /* (every lane is live from the start in LOCAL / SEMI_FREE_BEGIN) */
         const uint16_t* const en_o = r_en + ((e - o) & (gm - 1)) * slot;
         const uint16_t* const en_x = r_en + ((e - x) & (gm - 1)) * slot;
         const uint16_t* const ip_e = r_ip + ((e - ext) & (gi - 1)) * slot;
@@ -289,8 +296,8 @@ __global__ __launch_bounds__(64) void simd_ed_affine_kernel(const uint4* __restr
                 enew = simd_extend<W64>(simd_lane_mask<W64>(A0, A1, B0, B1, l - mid), st, len); /* :579-581 */
                 if (enew == len) { /* :589-603 */
                     const int diff = l < mid ? mid - l : l - mid;
-                    const int tc = e + (diff ? o + (diff - 1) * ext : 0);
-                    if (tc <= af_t && tc < conv) conv = tc;
+                    const int tc = converge_rule ? e + (diff ? o + (diff - 1) * ext : 0) : e; /* :604-608: final_ED, no threshold */
+                    if ((!converge_rule || tc <= af_t) && tc < conv) conv = tc;
                 }
             }
             en_w[l * TH] = (uint16_t)(enew + 2), ip_w[l * TH] = (uint16_t)(inew + 2), dp_w[l * TH] = (uint16_t)(dnew + 2);
@@ -341,7 +348,8 @@ ASM_DEV int quad_min(int v) {
 
 __global__ __launch_bounds__(64) void simd_ed_affine_quad_kernel(const uint4* __restrict__ planes, const uint32_t* __restrict__ lens,
                                                                  long n, int w4, int T, int af_t, int x, int o, int ext, int gm,
-                                                                 int gi, OutMap out) {
+                                                                 int gi, int mode /* as simd_ed_affine_kernel */, OutMap out) {
+    const bool all_start = mode == 1 || mode == 2, converge_rule = mode == 0 || mode == 2;
     constexpr int P = 16, PD = SIMD_QUAD_PD, PW = SIMD_QUAD_PW;
     typedef uint8_t EnT;
     extern __shared__ uint32_t s_afq[];
@@ -378,10 +386,24 @@ __global__ __launch_bounds__(64) void simd_ed_affine_quad_kernel(const uint4* __
     }
     leap_quad_fence();
     int result = live ? -2 : 0; /* -2: still running */
-    if (live) { /* e = 0: only the main lane has a start (ED_GLOBAL, :474-477,497-516); the four threads compute the same value */
+    if (live && !all_start) { /* e = 0: only the main lane has a start (ED_GLOBAL, SEMI_FREE_END; :474-477,497-516); the four
+                                 threads compute the same value */
         const int e0 = simd_quad_extend(pl, 0, 0, len);
         if (q == 0) r_en[mid * P] = (EnT)(e0 + 2);
-        if (e0 == len) result = 1000000;
+        if (e0 == len) result = converge_rule ? 1000000 : 0;
+    }
+    if (all_start) { /* LOCAL, SEMI_FREE_BEGIN: every lane starts at its distance from the main one; the lanes dealt to the quad */
+        int exact = 0;
+        if (live) {
+            for (int l = 1 + q; l <= 2 * T + 1; l += 4) {
+                const int dist = l < mid ? mid - l : l - mid;
+                const int e0 = simd_quad_extend(pl, l - mid, dist, len);
+                r_en[l * P] = (EnT)(e0 + 2);
+                if (e0 == len) exact = 1;
+            }
+        }
+        exact = quad_or(exact);
+        if (live && exact) result = converge_rule ? 1000000 : 0;
     }
     leap_quad_fence();
     for (int e = 1; e <= af_t; e++) {
@@ -389,7 +411,7 @@ __global__ __launch_bounds__(64) void simd_ed_affine_quad_kernel(const uint4* __
         int conv = 1000000;
         if (result == -2) {
             int dmax = e < o ? 0 : (e - o) / ext + 1; /* lanes a gap of this cost can have reached */
-            dmax = dmax > T ? T : dmax;
+            dmax = (dmax > T || all_start) ? T : dmax;
             const EnT* const en_o = r_en + ((e - o) & (gm - 1)) * slot;
             const EnT* const en_x = r_en + ((e - x) & (gm - 1)) * slot;
             const EnT* const ip_e = r_ip + ((e - ext) & (gi - 1)) * slot;
@@ -419,8 +441,8 @@ __global__ __launch_bounds__(64) void simd_ed_affine_quad_kernel(const uint4* __
                     enew = simd_quad_extend(pl, l - mid, st, len); /* :579-581 */
                     if (enew == len) { /* :589-603 */
                         const int diff = l < mid ? mid - l : l - mid;
-                        const int tc = e + (diff ? o + (diff - 1) * ext : 0);
-                        if (tc <= af_t && tc < conv) conv = tc;
+                        const int tc = converge_rule ? e + (diff ? o + (diff - 1) * ext : 0) : e;
+                        if ((!converge_rule || tc <= af_t) && tc < conv) conv = tc;
                     }
                 }
                 en_w[l * P] = (EnT)(enew + 2), ip_w[l * P] = (EnT)(inew + 2), dp_w[l * P] = (EnT)(dnew + 2);

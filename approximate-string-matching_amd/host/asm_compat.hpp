@@ -160,7 +160,7 @@ class SIMD_ED {
     bool affine_ = false;
     int gap_t_ = 0, af_t_ = 0, x_ = 1, o_ = 1, e_ = 1;
     bool af_shd_ = false;
-    int af_shd_t_ = 0;
+    int af_shd_t_ = 0, af_mode_ = 0;
     int32_t state_[3] = {0, 0, 0};
     std::string read_, ref_;
     int ed_ = -1;
@@ -170,7 +170,8 @@ public:
     // before (the reference object re-uses the tables of the pair before; see asm_simd_ed_affine_batch_async).
     void init_affine(int gap_threshold, int AF_threshold, ED_modes mode, int ms_penalty, int gap_open_penalty, int gap_ext_penalty,
                      bool SHD_enable = false, int SHD_threshold = 10) {
-        if (mode != ED_GLOBAL) throw std::runtime_error("SIMD_ED::init_affine: the accelerated path is ED_GLOBAL");
+        af_mode_ = mode == ED_GLOBAL ? ASM_LEAP_GLOBAL : mode == ED_LOCAL ? ASM_LEAP_LOCAL
+                   : mode == ED_SEMI_FREE_BEGIN ? ASM_LEAP_SEMI_FREE_BEGIN : ASM_LEAP_SEMI_FREE_END;
         affine_ = true, gap_t_ = gap_threshold, af_t_ = AF_threshold, x_ = ms_penalty, o_ = gap_open_penalty, e_ = gap_ext_penalty;
         af_shd_ = SHD_enable, af_shd_t_ = SHD_threshold; /* run_affine's SHD over the first 2*SHD_threshold+1 lane masks (:489-492) */
     }
@@ -193,8 +194,8 @@ public:
         int32_t out = -1;
         check(h, asm_batch_upload(h, 1, read_.data(), ro, ref_.data(), fo, ASM_GREEDY_CLEAN, &b));
         check(h, asm_device_malloc(h, sizeof(int32_t), &d));
-        const int rc = affine_ ? (af_shd_ ? asm_simd_ed_affine_shd_batch_async(h, b, gap_t_, af_t_, x_, o_, e_, af_shd_t_, (int32_t*)d)
-                                          : asm_simd_ed_affine_batch_async(h, b, gap_t_, af_t_, x_, o_, e_, (int32_t*)d))
+        const int rc = affine_ ? asm_simd_ed_affine_mode_batch_async(h, b, gap_t_, af_t_, x_, o_, e_, af_shd_ ? af_shd_t_ : -1, af_mode_,
+                                                                     (int32_t*)d)
                                : asm_simd_ed_batch_async(h, b, ed_t_, shd_ ? 1 : 0, ASM_FILTER_SEQUENTIAL, state_, (int32_t*)d);
         if (rc == ASM_OK) check(h, asm_memcpy_d2h(h, &out, d, sizeof(int32_t)));
         asm_device_free(h, d);

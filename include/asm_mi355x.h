@@ -261,6 +261,12 @@ int asm_simd_ed_affine_batch_async(asm_handle* h, const asm_batch* b, int gap_th
  * [0, min(16, gap_threshold)]: the reference object holds 2*gap_threshold+1 masks and would read past them.  Enqueue only. */
 int asm_simd_ed_affine_shd_batch_async(asm_handle* h, const asm_batch* b, int gap_threshold, int af_threshold, int x, int o, int e,
                                        int shd_threshold, int32_t* d_ed);
+/* ... and with init_affine's ED_modes argument (SIMD_ED.h:41,50): mode = ASM_LEAP_GLOBAL / LOCAL / SEMI_FREE_BEGIN / SEMI_FREE_END
+ * (the enum is LV's).  LOCAL and SEMI_FREE_BEGIN start every lane at generation 0 (SIMD_ED.cpp:476-478,497-516); LOCAL and
+ * SEMI_FREE_END accept any lane that reaches the end and d_ed[i] is final_ED there (:589-610,748-753) — 0, not 1000000, for a
+ * pair exact at generation 0.  shd_threshold < 0: SHD off.  Enqueue only. */
+int asm_simd_ed_affine_mode_batch_async(asm_handle* h, const asm_batch* b, int gap_threshold, int af_threshold, int x, int o, int e,
+                                        int shd_threshold, int mode, int32_t* d_ed);
 /* bit_vec_filter_avx(read planes, ref planes, min(m, 256), max_error) (LEAP_SIMD/SHD.h:17-18, SHD.cpp:241-322):
  * d_pass[i] = 1 when the pair survives the shifted-Hamming-distance filter, 0 when it is rejected.  max_error in
  * [0, 16].  Enqueue only. */

@@ -114,6 +114,10 @@ int orc_simd_ed_affine_batch(int64_t n, const char* reads, const uint32_t* read_
 /* ... with init_affine's SHD_enable / SHD_threshold (shd_t <= gap_t, <= 16): the mask-array SHD in front of run_affine */
 int orc_simd_ed_affine_shd_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
                                  int gap_t, int af_t, int x, int o, int ext, int shd_enable, int shd_t, int32_t* ed, uint8_t* pass);
+/* ... and with init_affine's ED_modes (numbering of ORC_LEAP_*) */
+int orc_simd_ed_affine_mode_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
+                                  int gap_t, int af_t, int x, int o, int ext, int shd_enable, int shd_t, int mode, int32_t* ed,
+                                  uint8_t* pass);
 
 int orc_shd_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
                   int max_error, int32_t* pass);

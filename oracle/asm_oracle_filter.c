@@ -270,8 +270,23 @@ int orc_simd_ed_affine_batch(int64_t n, const char* reads, const uint32_t* read_
  * beyond the object's array when it is larger (refused here).  A rejected pair does not pass; nothing else changes. */
 int orc_simd_ed_affine_shd_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
                                  int gap_t, int af_t, int x, int o, int ext, int shd_enable, int shd_t, int32_t* ed, uint8_t* pass) {
+    return orc_simd_ed_affine_mode_batch(n, reads, read_off, refs, ref_off, gap_t, af_t, x, o, ext, shd_enable, shd_t, ORC_LEAP_GLOBAL,
+                                         ed, pass);
+}
+
+/* ... and with init_affine's ED_modes argument (own numbering as orc_leap_mode_batch: 0 GLOBAL, 1 LOCAL, 2 SEMI_FREE_BEGIN,
+ * 3 SEMI_FREE_END).  LOCAL and SEMI_FREE_BEGIN give every lane a start at generation 0 (SIMD_ED.cpp:476-478) and generation 0
+ * sweeps all of them in ascending order (:497-516); LOCAL and SEMI_FREE_END accept any lane that reaches the end, without
+ * converge_ED's lane term and threshold (:589-610), and get_ED() returns final_ED there, converge_ED otherwise (:748-753) — so a
+ * pair exact at generation 0 reads 0 in LOCAL / SEMI_FREE_END and reset_affine's 1000000 in the other two. */
+int orc_simd_ed_affine_mode_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
+                                  int gap_t, int af_t, int x, int o, int ext, int shd_enable, int shd_t, int mode, int32_t* ed,
+                                  uint8_t* pass) {
     if (gap_t < 1 || gap_t > SIMD_MAX_T || af_t < 1 || af_t > SIMD_AF_MAX || x < 1 || o < 1 || ext < 1) return -1;
     if (shd_enable && (shd_t < 0 || shd_t > gap_t || shd_t > 16)) return -1;
+    if (mode < ORC_LEAP_GLOBAL || mode > ORC_LEAP_SEMI_FREE_END) return -1;
+    const int all_start = mode == ORC_LEAP_LOCAL || mode == ORC_LEAP_SEMI_FREE_BEGIN;
+    const int converge_rule = mode == ORC_LEAP_GLOBAL || mode == ORC_LEAP_SEMI_FREE_BEGIN;
     const int lanes = 2 * gap_t + 3, mid = gap_t + 1; /* SIMD_ED.cpp:452-453 */
     v256 hm[2 * SIMD_MAX_T + 3];
     typedef int row_t[SIMD_AF_MAX + 1];
@@ -305,11 +320,17 @@ int orc_simd_ed_affine_shd_batch(int64_t n, const char* reads, const uint32_t* r
         }
         for (int l = 0; l < lanes; l++) /* init_affine, :467-478 */
             for (int e = 0; e <= af_t; e++) start[l][e] = end[l][e] = ip[l][e] = dp[l][e] = -2;
-        start[mid][0] = 0;
-        int ok = 0, conv = 1000000; /* reset_affine, :483-486 */
-        end[mid][0] = count_id(hm[mid], 0, len) + start[mid][0]; /* :497-516: only the main lane has start >= 0 in ED_GLOBAL */
-        if (end[mid][0] == len) {
-            pass[i] = 1, ed[i] = conv;
+        int ok = 0, conv = 1000000, fin = 0; /* reset_affine, :483-486 */
+        int exact0 = 0;
+        for (int l = 1; l < lanes - 1 && !exact0; l++) { /* :476-478 and :497-516 */
+            const int dist = abs(l - mid);
+            if (dist != 0 && !all_start) continue;
+            start[l][0] = dist;
+            end[l][0] = count_id(hm[l], dist, len) + dist;
+            if (end[l][0] == len) exact0 = 1;
+        }
+        if (exact0) {
+            pass[i] = 1, ed[i] = converge_rule ? conv : 0; /* get_ED(): converge_ED (never written here) or final_ED = 0 */
             continue;
         }
         for (int e = 1; e <= af_t && !ok; e++) { /* :518-614 */
@@ -332,12 +353,13 @@ int orc_simd_ed_affine_shd_batch(int64_t n, const char* reads, const uint32_t* r
                     if (end[l][e] == len) {
                         const int diff = abs(mid - l);
                         const int tc = e + (diff ? o + (diff - 1) * ext : 0);
-                        if (tc <= af_t && tc < conv) ok = 1, conv = tc;
+                        if (!converge_rule) ok = 1, fin = e;
+                        else if (tc <= af_t && tc < conv) ok = 1, conv = tc;
                     }
                 }
             }
         }
-        pass[i] = (uint8_t)ok, ed[i] = ok ? conv : -1;
+        pass[i] = (uint8_t)ok, ed[i] = ok ? (converge_rule ? conv : fin) : -1;
     }
     free(st_);
     return 0;

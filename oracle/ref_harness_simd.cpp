@@ -59,9 +59,21 @@ int ref_simd_ed_affine_batch(int64_t n, const char* reads, const uint32_t* read_
                              int gap_t, int af_t, int x, int o, int e, int32_t* ed, uint8_t* pass) {
     return ref_simd_ed_affine_shd_batch(n, reads, read_off, refs, ref_off, gap_t, af_t, x, o, e, 0, 0, ed, pass);
 }
+int ref_simd_ed_affine_mode_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
+                                  int gap_t, int af_t, int x, int o, int e, int shd_enable, int shd_t, int mode, int32_t* ed,
+                                  uint8_t* pass);
 // ... with init_affine's SHD_enable / SHD_threshold (SIMD_ED.h:50)
 int ref_simd_ed_affine_shd_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
                                  int gap_t, int af_t, int x, int o, int e, int shd_enable, int shd_t, int32_t* ed, uint8_t* pass) {
+    return ref_simd_ed_affine_mode_batch(n, reads, read_off, refs, ref_off, gap_t, af_t, x, o, e, shd_enable, shd_t, 0, ed, pass);
+}
+// ... and its ED_modes (mode in the oracle's numbering: 0 GLOBAL, 1 LOCAL, 2 SEMI_FREE_BEGIN, 3 SEMI_FREE_END)
+int ref_simd_ed_affine_mode_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
+                                  int gap_t, int af_t, int x, int o, int e, int shd_enable, int shd_t, int mode, int32_t* ed,
+                                  uint8_t* pass) {
+    static const ED_modes map[4] = {ED_GLOBAL, ED_LOCAL, ED_SEMI_FREE_BEGIN, ED_SEMI_FREE_END};
+    if (mode < 0 || mode > 3) return -1;
+    const ED_modes ref_mode = map[mode];
     SIMD_ED* obj = new SIMD_ED;
     std::string s1, s2;
     for (int64_t i = 0; i < n; i++) {
@@ -70,7 +82,7 @@ int ref_simd_ed_affine_shd_batch(int64_t n, const char* reads, const uint32_t* r
         s1.assign(reads + read_off[i], m);
         s2.assign(refs + ref_off[i], nn);
         int length = m > 256 ? 256 : m;
-        obj->init_affine(gap_t, af_t, ED_GLOBAL, x, o, e, shd_enable != 0, shd_t);
+        obj->init_affine(gap_t, af_t, ref_mode, x, o, e, shd_enable != 0, shd_t);
         obj->load_reads((char*)s1.c_str(), (char*)s2.c_str(), length);
         obj->calculate_masks();
         obj->reset(); /* -> reset_affine / run_affine: affine_mode is set by init_affine */

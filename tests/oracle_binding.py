@@ -78,6 +78,7 @@ class Oracle:
         lib.orc_shd_batch.argtypes = b5 + [_i, _vp]
         lib.orc_simd_ed_affine_batch.argtypes = b5 + [_i] * 5 + [_vp, _vp]
         lib.orc_simd_ed_affine_shd_batch.argtypes = b5 + [_i] * 7 + [_vp, _vp]
+        lib.orc_simd_ed_affine_mode_batch.argtypes = b5 + [_i] * 8 + [_vp, _vp]
 
     def set_threads(self, n):
         return self.lib.orc_set_threads(n)
@@ -201,14 +202,15 @@ class Oracle:
         assert rc == 0, rc
         return ed, raw, ps
 
-    def simd_ed_affine(self, hb, gap_t=3, af_t=60, x=2, o=3, e=1, shd_t=None):
+    def simd_ed_affine(self, hb, gap_t=3, af_t=60, x=2, o=3, e=1, shd_t=None, mode=0):
         """(ed, pass): SIMD_ED affine mode, clean; ed = get_ED() (1000000 for a pair exact at e = 0) when the pair passes else -1.
-        shd_t: init_affine's SHD_threshold with SHD_enable = true (None: SHD off, init_affine's default)."""
+        shd_t: init_affine's SHD_threshold with SHD_enable = true (None: SHD off, init_affine's default); mode: its ED_modes in
+        the oracle's numbering (0 GLOBAL, 1 LOCAL, 2 SEMI_FREE_BEGIN, 3 SEMI_FREE_END)."""
         keep, args = _batch_args(hb)
         ed = np.zeros(hb.n, np.int32)
         ps = np.zeros(hb.n, np.uint8)
-        rc = self.lib.orc_simd_ed_affine_shd_batch(*args, gap_t, af_t, x, o, e, 0 if shd_t is None else 1,
-                                                   0 if shd_t is None else int(shd_t), ed.ctypes.data, ps.ctypes.data)
+        rc = self.lib.orc_simd_ed_affine_mode_batch(*args, gap_t, af_t, x, o, e, 0 if shd_t is None else 1,
+                                                    0 if shd_t is None else int(shd_t), int(mode), ed.ctypes.data, ps.ctypes.data)
         assert rc == 0, rc
         return ed, ps
 
@@ -245,6 +247,7 @@ class ReferenceSimd:
         lib.ref_shd_batch.argtypes = b5 + [_i, _vp]
         lib.ref_simd_ed_affine_batch.argtypes = b5 + [_i] * 5 + [_vp, _vp]
         lib.ref_simd_ed_affine_shd_batch.argtypes = b5 + [_i] * 7 + [_vp, _vp]
+        lib.ref_simd_ed_affine_mode_batch.argtypes = b5 + [_i] * 8 + [_vp, _vp]
 
     def simd_ed(self, hb, ed_t=3, shd=True):
         """(get_ED() raw, check_pass()) per pair, run in batch order after the harness's warm-up pair."""
@@ -254,14 +257,14 @@ class ReferenceSimd:
         assert self.lib.ref_simd_ed_batch(*args, ed_t, 1 if shd else 0, ed.ctypes.data, ps.ctypes.data) == 0
         return ed, ps
 
-    def simd_ed_affine(self, hb, gap_t=3, af_t=60, x=2, o=3, e=1, shd_t=None):
+    def simd_ed_affine(self, hb, gap_t=3, af_t=60, x=2, o=3, e=1, shd_t=None, mode=0):
         """(get_ED(), check_pass()) per pair with init_affine before every pair (clean tables); shd_t: SHD_enable = true with that
-        SHD_threshold."""
+        SHD_threshold; mode: ED_modes in the oracle's numbering."""
         keep, args = _batch_args(hb)
         ed = np.zeros(hb.n, np.int32)
         ps = np.zeros(hb.n, np.uint8)
-        assert self.lib.ref_simd_ed_affine_shd_batch(*args, gap_t, af_t, x, o, e, 0 if shd_t is None else 1,
-                                                     0 if shd_t is None else int(shd_t), ed.ctypes.data, ps.ctypes.data) == 0
+        assert self.lib.ref_simd_ed_affine_mode_batch(*args, gap_t, af_t, x, o, e, 0 if shd_t is None else 1,
+                                                      0 if shd_t is None else int(shd_t), int(mode), ed.ctypes.data, ps.ctypes.data) == 0
         return ed, ps
 
     def shd(self, hb, max_error=3):

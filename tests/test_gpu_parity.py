@@ -603,6 +603,23 @@ def test_leap_ed_modes(asm, engine, oracle, wl, n, mode):
     assert np.array_equal(engine.align(batch, asm.LEAP, asm.Params.default(k=3, leap_mode=asm.LEAP_GLOBAL))[ok], oracle.leap(hb, 3)[ok])
 
 
+@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("wl,n", [("C2", 8000), ("C5", 6000), ("C3", 3000)])
+def test_simd_ed_affine_filter_ed_modes(asm, engine, oracle, wl, n, mode):
+    """init_affine's ED_modes (LOCAL / SEMI_FREE_BEGIN / SEMI_FREE_END) in both kernel forms, with and without the SHD pre-filter;
+    get_ED() is final_ED in LOCAL and SEMI_FREE_END (0 for a pair exact at generation 0), converge_ED in the other two."""
+    cfg, _, _ = asm.workload(wl)
+    hb = asm.generate_pairs(cfg, 59, n)
+    batch = engine.upload(hb, asm.GREEDY_CLEAN)
+    for g, af, x, o, e, st in ((3, 60, 2, 3, 1, None), (6, 30, 1, 1, 1, 2), (12, 120, 4, 6, 2, None), (20, 40, 1, 2, 1, 5), (32, 200, 15, 15, 15, None)):
+        want, _ = oracle.simd_ed_affine(hb, g, af, x, o, e, shd_t=st, mode=mode)
+        got = engine.simd_ed_affine(batch, g, af, x, o, e, shd_threshold=st, mode=mode)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (wl, mode, g, af, x, o, e, st, bad[:5], got[bad[:5]], want[bad[:5]])
+    with pytest.raises(asm.AsmError):
+        engine.simd_ed_affine(batch, 3, 60, 2, 3, 1, mode=4)
+
+
 def test_filters_ignore_the_stale_tails_of_sequential_batches(asm, engine, oracle):
     """A batch packed for Greedy's sequential mode keeps the reference's stale buffer tails beyond each string's end; NW, LEAP
     and the three filters must not see them (mixed lengths: long pairs leave long tails for the short ones that follow)."""

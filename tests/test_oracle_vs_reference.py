@@ -196,3 +196,25 @@ def test_leap_ed_modes_match_the_compiled_reference(asm, oracle, mode):
             differs_from_global += int((got[ok] != oracle.leap(hb, k, x, o, e)[ok]).sum())
     if mode in (1, 2):
         assert differs_from_global > 0  # free begin gaps really change results
+
+
+@pytest.mark.skipif(not oracle_binding.have_reference_simd(), reason="oracle/_ref/libasm_ref_simd.so not built")
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_simd_ed_affine_ed_modes_match_the_compiled_reference(asm, oracle, mode):
+    """init_affine's ED_modes argument (SIMD_ED.cpp:476-478,497-516,589-610,748-753): every lane starts at generation 0 in LOCAL
+    and SEMI_FREE_BEGIN; LOCAL and SEMI_FREE_END accept any lane that reaches the end and report final_ED — a pair exact at
+    generation 0 reads 0 there and reset_affine's 1000000 in the other two.  Clean form (init_affine before every pair), with and
+    without the SHD pre-filter."""
+    from tests.util import random_ragged_batch
+    ref = oracle_binding.load_reference_simd()
+    batches = [asm.generate_pairs(asm.workload(wl)[0], 41, n) for wl, n in (("C2", 2000), ("C3", 800), ("C4", 2000), ("C5", 1500))]
+    batches.append(random_ragged_batch(asm, 8, 1200, 0, 300, err=0.15))
+    saw_exact = False
+    for hb in batches:
+        for g, af, x, o, e, st in ((3, 60, 2, 3, 1, None), (6, 30, 1, 1, 1, 2), (12, 120, 4, 6, 2, None), (20, 40, 1, 2, 1, 5)):
+            o_ed, o_ps = oracle.simd_ed_affine(hb, g, af, x, o, e, shd_t=st, mode=mode)
+            r_ed, r_ps = ref.simd_ed_affine(hb, g, af, x, o, e, shd_t=st, mode=mode)
+            assert np.array_equal(o_ps, r_ps), (mode, g, af, x, o, e, st)
+            assert np.array_equal(o_ed, np.where(r_ps == 1, r_ed, -1)), (mode, g, af, x, o, e, st)
+            saw_exact |= bool(((o_ed == 0) | (o_ed == 1000000)).any())
+    assert saw_exact

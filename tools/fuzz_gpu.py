@@ -67,6 +67,9 @@ while time.time() - t0 < budget:
         st = int(rng.integers(0, min(g, 16) + 1))  # init_affine's SHD_threshold, SHD_enable = true
         want_s, _ = orc.simd_ed_affine(hb, g, af, ax, ao, ae, shd_t=st)
         res.append(("simd_af_shd", bool(np.array_equal(eng.simd_ed_affine(batch, g, af, ax, ao, ae, shd_threshold=st), want_s))))
+        am = int(rng.integers(1, 4))  # init_affine's ED_modes
+        want_m, _ = orc.simd_ed_affine(hb, g, af, ax, ao, ae, mode=am)
+        res.append((f"simd_af_m{am}", bool(np.array_equal(eng.simd_ed_affine(batch, g, af, ax, ao, ae, mode=am), want_m))))
     ok = all(v for _, v in res)
     bad += 0 if ok else 1
     print(f"case {case:3d} {desc:22s} n={hb.n:5d} k={k:2d} pen=({x},{o},{e}) mode={mode} semi={int(semi)}: " + " ".join(f"{a}={'ok' if v else 'FAIL'}" for a, v in res), flush=True)
