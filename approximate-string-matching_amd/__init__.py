@@ -156,6 +156,7 @@ def load_library() -> ctypes.CDLL:
         "asm_cigar_format": (i32, [vp, i32, i32, vp, c.c_size_t]),
         "asm_coverage": (i32, [vp, vp, c.POINTER(Params), vp, i32, vp, i32, vp, vp, i32, vp, vp]),
         "asm_simd_ed_batch_async": (i32, [vp, vp, i32, i32, i32, vp, vp]),
+        "asm_simd_ed_mode_batch_async": (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
         "asm_simd_ed_affine_batch_async": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
         "asm_simd_ed_affine_shd_batch_async": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
         "asm_simd_ed_affine_mode_batch_async": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
@@ -475,21 +476,23 @@ class Engine:
 
     # ---- filtering stage: bit-parallel LEAP (SIMD_ED) and SHD (LEAP_SIMD/main.cpp:95-101,186-195) ----
     def simd_ed_async(self, batch: DeviceBatch, ed_threshold: int, d_ed: int, shd: bool = True, mode: int = FILTER_CLEAN,
-                      state: Optional[Sequence[int]] = None) -> Optional[Tuple[int, ...]]:
+                      state: Optional[Sequence[int]] = None, ed_mode: int = 0) -> Optional[Tuple[int, ...]]:
         """SIMD_ED::init_levenshtein(ed_threshold, ED_GLOBAL, shd) + load_reads/calculate_masks/reset/run per pair:
         d_ed[i] = get_ED() when check_pass() else -1.  state = (final_ED, lane distance, converge_ED) carried into the
-        first pair in FILTER_SEQUENTIAL mode; returns the state after the last pair (for the next chunk of the same file)."""
+        first pair in FILTER_SEQUENTIAL mode; returns the state after the last pair (for the next chunk of the same file).
+        ed_mode: init_levenshtein's ED_modes (LEAP_GLOBAL, the filter driver's; LEAP_LOCAL / LEAP_SEMI_FREE_BEGIN / LEAP_SEMI_FREE_END)."""
         st = None
         if state is not None:
             st = (ctypes.c_int32 * 3)(*[int(v) for v in state])
-        self._chk(self.lib.asm_simd_ed_batch_async(self.h, batch.ptr, int(ed_threshold), 1 if shd else 0, int(mode), st, d_ed))
+        self._chk(self.lib.asm_simd_ed_mode_batch_async(self.h, batch.ptr, int(ed_threshold), 1 if shd else 0, int(mode), int(ed_mode),
+                                                        st, d_ed))
         return tuple(st) if st is not None else None
 
     def simd_ed(self, batch: DeviceBatch, ed_threshold: int, shd: bool = True, mode: int = FILTER_CLEAN,
-                state: Optional[Sequence[int]] = None) -> np.ndarray:
+                state: Optional[Sequence[int]] = None, ed_mode: int = 0) -> np.ndarray:
         d_out = self.malloc(4 * max(batch.n, 1))
         try:
-            self.simd_ed_async(batch, ed_threshold, d_out, shd, mode, state)
+            self.simd_ed_async(batch, ed_threshold, d_out, shd, mode, state, ed_mode)
             return self.to_host(d_out, batch.n)
         finally:
             self.free(d_out)

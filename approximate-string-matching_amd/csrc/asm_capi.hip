@@ -611,13 +611,13 @@ static int cover_bucket(asm_handle* h, const asm_bucket& b, const asm_params* p,
 
 /* SIMD_ED events of one bucket (asm_filter.h) */
 template <int W64>
-static int launch_simd_ed_events(asm_handle* h, const asm_bucket& b, int T, int shd, OutMap ev) {
+static int launch_simd_ed_events(asm_handle* h, const asm_bucket& b, int T, int shd, OutMap ev, int ed_mode = 0) {
     const dim3 grid((unsigned)((b.n + SIMD_ED_THREADS - 1) / SIMD_ED_THREADS)), block(SIMD_ED_THREADS);
 #define SIMD_ED_CASE(TT)                                                                                                \
     case TT:                                                                                                            \
-        hipLaunchKernelGGL((simd_ed_kernel<TT, W64>), grid, block, 0, h->stream, b.planes, b.lens, (long)b.n, b.w4, T, shd, ev); \
+        hipLaunchKernelGGL((simd_ed_kernel<TT, W64>), grid, block, 0, h->stream, b.planes, b.lens, (long)b.n, b.w4, T, shd, 0, ev); \
         break;
-    switch (T <= ASM_FILTER_REG_MAX_T ? T : 0) {
+    switch ((T <= ASM_FILTER_REG_MAX_T && ed_mode != 1 && ed_mode != 2) ? T : 0) { /* every lane live from generation 0: run-time form */
         SIMD_ED_CASE(1)
         SIMD_ED_CASE(2)
         SIMD_ED_CASE(3)
@@ -629,7 +629,7 @@ static int launch_simd_ed_events(asm_handle* h, const asm_bucket& b, int T, int 
         default: {
             const size_t lds = (size_t)2 * (2 * T + 3) * SIMD_ED_THREADS * sizeof(short);
             hipLaunchKernelGGL((simd_ed_kernel<0, W64>), grid, block, lds, h->stream, b.planes, b.lens, (long)b.n, b.w4, T, shd,
-                               ev);
+                               ed_mode, ev);
         }
     }
 #undef SIMD_ED_CASE
@@ -1732,7 +1732,14 @@ int asm_align_batch(asm_handle* h, int aligner, int64_t n, const char* reads, co
 
 int asm_simd_ed_batch_async(asm_handle* h, const asm_batch* b, int ed_threshold, int shd_enable, int mode,
                             int32_t* state, int32_t* d_ed) {
+    return asm_simd_ed_mode_batch_async(h, b, ed_threshold, shd_enable, mode, ASM_LEAP_GLOBAL, state, d_ed);
+}
+
+int asm_simd_ed_mode_batch_async(asm_handle* h, const asm_batch* b, int ed_threshold, int shd_enable, int mode, int ed_mode,
+                                 int32_t* state, int32_t* d_ed) {
     if (!h || !b || !d_ed) return fail(h, ASM_EINVAL, "asm_simd_ed_batch_async: NULL argument");
+    if (ed_mode < ASM_LEAP_GLOBAL || ed_mode > ASM_LEAP_SEMI_FREE_END)
+        return fail(h, ASM_EINVAL, "asm_simd_ed_mode_batch_async: ed_mode must be one of ASM_LEAP_GLOBAL/LOCAL/SEMI_FREE_BEGIN/SEMI_FREE_END");
     if (ed_threshold < 1 || ed_threshold > ASM_FILTER_MAX_T)
         return fail(h, ASM_EINVAL, "asm_simd_ed_batch_async: ED threshold must be in [1, 32]");
     if (shd_enable && ed_threshold > ASM_SHD_MAX_ERROR)
@@ -1748,12 +1755,17 @@ int asm_simd_ed_batch_async(asm_handle* h, const asm_batch* b, int ed_threshold,
         OutMap ev;
         ev.out = d_ed;
         ev.order = b->bk[q].order;
-        rc = b->bk[q].maxlen <= 128 ? launch_simd_ed_events<2>(h, b->bk[q], ed_threshold, shd_enable ? 1 : 0, ev)
-                                    : launch_simd_ed_events<4>(h, b->bk[q], ed_threshold, shd_enable ? 1 : 0, ev);
+        rc = b->bk[q].maxlen <= 128 ? launch_simd_ed_events<2>(h, b->bk[q], ed_threshold, shd_enable ? 1 : 0, ev, ed_mode)
+                                    : launch_simd_ed_events<4>(h, b->bk[q], ed_threshold, shd_enable ? 1 : 0, ev, ed_mode);
     }
     if (rc) return rc;
     const long n = (long)b->n;
     const dim3 g(grid_for(b->n)), t(ASM_BLOCK);
+    if (ed_mode == ASM_LEAP_LOCAL || ed_mode == ASM_LEAP_SEMI_FREE_END) { /* no converge_ED, no carried state: SEQUENTIAL = CLEAN */
+        hipLaunchKernelGGL(simd_ed_final_kernel, g, t, 0, h->stream, d_ed, n);
+        HIPCHK(h, hipGetLastError());
+        return ASM_OK;
+    }
     if (mode == ASM_FILTER_CLEAN) {
         hipLaunchKernelGGL(simd_ed_clean_kernel, g, t, 0, h->stream, d_ed, n, ed_threshold);
         HIPCHK(h, hipGetLastError());

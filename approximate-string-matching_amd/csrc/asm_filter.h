@@ -18,7 +18,8 @@
 // events of one pair (S2)
 #define EV_REJECTED (-1)  /* SHD said no: verdict fail, state untouched                                             */
 #define EV_NOT_REACHED (-2) /* no lane reached the end within T generations: verdict = the carried state's             */
-#define EV_EXACT (-3)     /* the main lane reached the end at e = 0: passes, sets (final_ED, lane) = (0, 0) only       */
+#define EV_EXACT (-3)     /* the main lane reached the end at e = 0: passes, sets (final_ED, lane) = (0, 0) only;
+                             EV_EXACT - d: the same on a lane d off the main one (ED_modes LOCAL / SEMI_FREE_BEGIN)          */
 /* >= 0: reached at generation fe on a lane fd away from the main one: fe | fd << 8                                     */
 
 // bits move away from index 0 by s in [0, 63], each 128-bit half separately when W64 = 4 (S1)
@@ -98,7 +99,12 @@ ASM_DEV VW<W64> vw_from(int cnt) { /* bits cnt.. set: MASK_AVX_BEG row cnt-1 (ma
 template <int TT, int W64>
 __global__ __launch_bounds__(SIMD_ED_THREADS) void simd_ed_kernel(const uint4* __restrict__ planes,
                                                                   const uint32_t* __restrict__ lens, long n, int w4, int t_rt,
-                                                                  int shd_enable, OutMap events) {
+                                                                  int shd_enable, int ed_mode /* ASM_LEAP_*; TT == 0 only */,
+                                                                  OutMap events) {
+    // init_levenshtein's ED_modes: LOCAL (1) and SEMI_FREE_BEGIN (2) keep every lane live from generation 0, starting at its
+    // distance from the main lane (SIMD_ED.cpp:246-266: start[i][0] = ED, cur_ED[i] = 0); GLOBAL and SEMI_FREE_END let lane l
+    // join at generation |l - mid|.  The compile-time-T instantiations serve GLOBAL / SEMI_FREE_END only.
+    const bool all_start = TT == 0 && (ed_mode == 1 || ed_mode == 2);
     constexpr int NLC = TT > 0 ? 2 * TT + 1 : 1;
     extern __shared__ short s_end[]; /* TT = 0: [2][2T+3][threads] */
     const int T = TT > 0 ? TT : t_rt;
@@ -177,15 +183,16 @@ __global__ __launch_bounds__(SIMD_ED_THREADS) void simd_ed_kernel(const uint4* _
         short* const col = s_end + t;
 #define END_AT(g, l) col[((g)*rows + (l)) * SIMD_ED_THREADS]
         for (int l = 0; l < rows; l++) END_AT(0, l) = -2, END_AT(1, l) = -2;
-        {
-            const VW<W64> h = simd_lane_mask<W64>(A0, A1, B0, B1, 0);
-            const int e0 = simd_extend<W64>(h, 0, len);
-            END_AT(0, T + 1) = (short)e0;
-            if (e0 == len) ev = EV_EXACT;
+        for (int j = all_start ? 0 : T; j <= (all_start ? 2 * T : T) && ev == EV_NOT_REACHED; j++) { /* cur_ED == 0, ascending */
+            const int dist = j < T ? T - j : j - T;
+            const VW<W64> h = simd_lane_mask<W64>(A0, A1, B0, B1, j - T);
+            const int e0 = simd_extend<W64>(h, dist, len);
+            END_AT(0, j + 1) = (short)e0;
+            if (e0 == len) ev = EV_EXACT - dist;
         }
         for (int e = 1; e <= T && ev == EV_NOT_REACHED; e++) {
             const int gp = (e - 1) & 1, gc = e & 1;
-            for (int j = T - e; j <= T + e; j++) { /* lanes with distance <= e, ascending */
+            for (int j = all_start ? 0 : T - e; j <= (all_start ? 2 * T : T + e); j++) { /* lanes with cur_ED == e, ascending */
                 int st = (int)END_AT(gp, j + 1) + 1;
                 const int up = (int)END_AT(gp, j) + (j >= T ? 1 : 0), dn = (int)END_AT(gp, j + 2) + (j <= T ? 1 : 0);
                 st = up > st ? up : st;
@@ -493,12 +500,21 @@ __global__ __launch_bounds__(ASM_BLOCK) void simd_ed_clean_kernel(int32_t* __res
     if (i >= n) return;
     const int ev = ev_to_ed[i];
     int ed = -1;
-    if (ev == EV_EXACT) ed = 0;
+    if (ev <= EV_EXACT) ed = 0;
     if (ev >= 0) {
         const int conv = (ev & 0xff) + (ev >> 8);
         ed = conv <= T ? conv : -1;
     }
     ev_to_ed[i] = ed;
+}
+
+// ED_modes LOCAL and SEMI_FREE_END: a pair passes exactly when a lane reached the end, and get_ED() is final_ED
+// (SIMD_ED.cpp:348-351 does not apply, :748-753) — no state of an earlier pair is read
+__global__ __launch_bounds__(ASM_BLOCK) void simd_ed_final_kernel(int32_t* __restrict__ ev_to_ed, long n) {
+    const long i = (long)blockIdx.x * ASM_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int ev = ev_to_ed[i];
+    ev_to_ed[i] = ev <= EV_EXACT ? 0 : (ev >= 0 ? (ev & 0xff) : -1);
 }
 
 // sequential mode, step 1: key of the (final_ED, lane) chain — pairs that set it carry fe | fd << 8, the others -1
@@ -507,7 +523,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void simd_ed_setter_kernel(const int32_t
     const long i = (long)blockIdx.x * ASM_BLOCK + threadIdx.x;
     if (i >= n) return;
     const int e = ev[i];
-    key[i] = e == EV_EXACT ? 0 : (e >= 0 ? e : -1);
+    key[i] = e <= EV_EXACT ? ((EV_EXACT - e) << 8) : (e >= 0 ? e : -1); /* exact: final_ED = 0 on a lane EV_EXACT - e off the main one */
 }
 
 // step 2 (after the last-setter scan of key): converge_ED is rewritten by pairs that run to the end of run_levenshtein
@@ -534,7 +550,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void simd_ed_verdict_kernel(int32_t* __r
     if (i >= n) return;
     const int e = ev_to_ed[i];
     int ed = -1;
-    if (e == EV_EXACT) { /* passes; get_ED() is the converge_ED left by the pairs before it (S2) */
+    if (e <= EV_EXACT) { /* passes; get_ED() is the converge_ED left by the pairs before it (S2) */
         const int c = i > 0 ? conv_after[i - 1] : -1;
         ed = c >= 0 ? c : init_conv;
     } else if (e != EV_REJECTED) {

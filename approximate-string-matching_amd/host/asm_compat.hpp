@@ -160,7 +160,7 @@ class SIMD_ED {
     bool affine_ = false;
     int gap_t_ = 0, af_t_ = 0, x_ = 1, o_ = 1, e_ = 1;
     bool af_shd_ = false;
-    int af_shd_t_ = 0, af_mode_ = 0;
+    int af_shd_t_ = 0, af_mode_ = 0, lev_mode_ = 0;
     int32_t state_[3] = {0, 0, 0};
     std::string read_, ref_;
     int ed_ = -1;
@@ -176,7 +176,8 @@ public:
         af_shd_ = SHD_enable, af_shd_t_ = SHD_threshold; /* run_affine's SHD over the first 2*SHD_threshold+1 lane masks (:489-492) */
     }
     void init_levenshtein(int ED_threshold, ED_modes mode = ED_GLOBAL, bool SHD_enable = true) {
-        if (mode != ED_GLOBAL) throw std::runtime_error("SIMD_ED::init_levenshtein: the accelerated path is ED_GLOBAL (main.cpp:97)");
+        lev_mode_ = mode == ED_GLOBAL ? ASM_LEAP_GLOBAL : mode == ED_LOCAL ? ASM_LEAP_LOCAL
+                    : mode == ED_SEMI_FREE_BEGIN ? ASM_LEAP_SEMI_FREE_BEGIN : ASM_LEAP_SEMI_FREE_END;
         ed_t_ = ED_threshold, shd_ = SHD_enable, affine_ = false;
     }
     void load_reads(char* read, char* ref, int length) {  // strncpy semantics: NUL-terminated, at most `length` characters
@@ -196,7 +197,7 @@ public:
         check(h, asm_device_malloc(h, sizeof(int32_t), &d));
         const int rc = affine_ ? asm_simd_ed_affine_mode_batch_async(h, b, gap_t_, af_t_, x_, o_, e_, af_shd_ ? af_shd_t_ : -1, af_mode_,
                                                                      (int32_t*)d)
-                               : asm_simd_ed_batch_async(h, b, ed_t_, shd_ ? 1 : 0, ASM_FILTER_SEQUENTIAL, state_, (int32_t*)d);
+                               : asm_simd_ed_mode_batch_async(h, b, ed_t_, shd_ ? 1 : 0, ASM_FILTER_SEQUENTIAL, lev_mode_, state_, (int32_t*)d);
         if (rc == ASM_OK) check(h, asm_memcpy_d2h(h, &out, d, sizeof(int32_t)));
         asm_device_free(h, d);
         asm_batch_free(h, b);

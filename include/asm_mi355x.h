@@ -245,6 +245,12 @@ int asm_stream_seq_file(asm_handle* h, const char* path, const asm_params* p, in
 #define ASM_FILTER_CLEAN 1
 int asm_simd_ed_batch_async(asm_handle* h, const asm_batch* b, int ed_threshold, int shd_enable, int mode,
                             int32_t* state, int32_t* d_ed);
+/* The same with init_levenshtein's ED_modes argument (SIMD_ED.h:41,49; ed_mode = ASM_LEAP_GLOBAL / LOCAL / SEMI_FREE_BEGIN /
+ * SEMI_FREE_END): LOCAL and SEMI_FREE_BEGIN keep every lane live from generation 0 (SIMD_ED.cpp:246-266); LOCAL and
+ * SEMI_FREE_END pass exactly when a lane reaches the end, d_ed[i] = final_ED, and neither read nor change `state`
+ * (:348-351,748-753 — `mode` makes no difference there); SEMI_FREE_BEGIN follows GLOBAL's rules, carried state included. */
+int asm_simd_ed_mode_batch_async(asm_handle* h, const asm_batch* b, int ed_threshold, int shd_enable, int mode, int ed_mode,
+                                 int32_t* state, int32_t* d_ed);
 /* SIMD_ED in affine mode (LEAP_SIMD/SIMD_ED.h:50, SIMD_ED.cpp:435-616): init_affine(gap_threshold, af_threshold, ED_GLOBAL, x,
  * o, e) then, per pair, load_reads(read, ref, min(m, 256)) / calculate_masks() / reset() / run() / check_pass() / get_ED(), in
  * CLEAN form: every pair starts from the tables init_affine leaves.  (The reference object keeps its I/D/end tables from pair to

@@ -105,6 +105,10 @@ int orc_coverage_batch(int64_t n, const char* reads, const uint32_t* read_off, c
 int orc_simd_ed_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
                       int ed_t, int shd_enable, int mode, const int32_t* state, int32_t* ed, int32_t* ed_raw,
                       uint8_t* pass);
+/* ... with init_levenshtein's ED_modes (numbering of ORC_LEAP_*, declared below) */
+int orc_simd_ed_edmode_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
+                             int ed_t, int shd_enable, int mode, int ed_mode, const int32_t* state, int32_t* ed, int32_t* ed_raw,
+                             uint8_t* pass);
 
 /* SHD on the pair's 2-bit planes: bit_vec_filter_avx(read0, read1, ref0, ref1, min(m,256), max_error)
  * (GASMA/benchmark/LEAP_SIMD/SHD.cpp:95-143,241-322; popcount.cpp:44-76,78-110).  pass[i] in {0,1}. */

@@ -184,7 +184,21 @@ static int count_id(v256 mask, int start, int len) {
 int orc_simd_ed_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
                       int ed_t, int shd_enable, int mode, const int32_t* state, int32_t* ed, int32_t* ed_raw,
                       uint8_t* pass) {
+    return orc_simd_ed_edmode_batch(n, reads, read_off, refs, ref_off, ed_t, shd_enable, mode, ORC_LEAP_GLOBAL, state, ed, ed_raw, pass);
+}
+
+/* ... with init_levenshtein's ED_modes argument (numbering of ORC_LEAP_*).  LOCAL and SEMI_FREE_BEGIN: every lane is live from
+ * generation 0, starting at its distance from the main lane (SIMD_ED.cpp:246-266: start[i][0] = ED, cur_ED[i] = 0); GLOBAL and
+ * SEMI_FREE_END: lane l joins at generation |l - mid|.  GLOBAL and SEMI_FREE_BEGIN end with converge_ED = final_ED + lane
+ * distance <= ED_t (:348-351, the stale-state rule S2 included) and get_ED() = converge_ED; LOCAL and SEMI_FREE_END pass exactly
+ * when a lane reaches the end and get_ED() = final_ED (:748-753) — no state of an earlier pair is ever read there. */
+int orc_simd_ed_edmode_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
+                             int ed_t, int shd_enable, int mode, int ed_mode, const int32_t* state, int32_t* ed, int32_t* ed_raw,
+                             uint8_t* pass) {
     if (ed_t < 0 || ed_t > SIMD_MAX_T || (shd_enable && ed_t > 16)) return -1;
+    if (ed_mode < ORC_LEAP_GLOBAL || ed_mode > ORC_LEAP_SEMI_FREE_END) return -1;
+    const int all_start = ed_mode == ORC_LEAP_LOCAL || ed_mode == ORC_LEAP_SEMI_FREE_BEGIN;
+    const int converge_rule = ed_mode == ORC_LEAP_GLOBAL || ed_mode == ORC_LEAP_SEMI_FREE_BEGIN;
     const int lanes = 2 * ed_t + 3, mid = ed_t + 1; /* SIMD_ED.cpp:222-223; lanes 0 and lanes-1 are guards */
     int fe = state ? state[0] : 0, fd = state ? state[1] : 0, conv = state ? state[2] : 0;
     v256 hm[2 * SIMD_MAX_T + 3];
@@ -219,16 +233,22 @@ int orc_simd_ed_batch(int64_t n, const char* reads, const uint32_t* read_off, co
         }
         for (int l = 0; l < lanes; l++)
             for (int e = 0; e <= ed_t; e++) end[l][e] = -2; /* entries never written hold init_levenshtein's -2 */
-        end[mid][0] = count_id(hm[mid], 0, len);          /* SIMD_ED.cpp:277-299 */
-        if (end[mid][0] == len) {
-            fe = 0, fd = 0; /* returns with ED_pass = true; converge_ED is NOT rewritten (S2) */
-            pass[i] = 1, ed[i] = conv;
-            if (ed_raw) ed_raw[i] = conv;
+        int exact0 = 0, exact_d = 0;
+        for (int l = 1; l < lanes - 1 && !exact0; l++) { /* SIMD_ED.cpp:277-299: the lanes with cur_ED == 0, ascending */
+            const int dist = abs(l - mid);
+            if (dist != 0 && !all_start) continue;
+            end[l][0] = dist + count_id(hm[l], dist, len);
+            if (end[l][0] == len) exact0 = 1, exact_d = dist;
+        }
+        if (exact0) {
+            fe = 0, fd = exact_d; /* returns with ED_pass = true; converge_ED is NOT rewritten (S2) */
+            pass[i] = 1, ed[i] = converge_rule ? conv : 0;
+            if (ed_raw) ed_raw[i] = converge_rule ? conv : 0;
             continue;
         }
         for (int e = 1; e <= ed_t && !reached; e++) { /* SIMD_ED.cpp:301-346 */
             for (int l = 1; l < lanes - 1; l++) {
-                if (abs(l - mid) > e) continue; /* cur_ED[l] == e */
+                if (!all_start && abs(l - mid) > e) continue; /* cur_ED[l] == e */
                 const int top = l >= mid, bot = l <= mid;
                 int st = end[l][e - 1] + 1;
                 if (end[l - 1][e - 1] + top > st) st = end[l - 1][e - 1] + top;
@@ -240,7 +260,12 @@ int orc_simd_ed_batch(int64_t n, const char* reads, const uint32_t* read_off, co
                 }
             }
         }
-        (void)reached;
+        if (!converge_rule) { /* LOCAL, SEMI_FREE_END: ED_pass as the sweep left it, get_ED() = final_ED */
+            ok = reached;
+            pass[i] = (uint8_t)ok, ed[i] = ok ? fe : -1;
+            if (ed_raw) ed_raw[i] = fe;
+            continue;
+        }
         conv = fe + fd; /* SIMD_ED.cpp:348-351 — with stale fe/fd when the end was never reached (S2) */
         ok = conv <= ed_t;
         pass[i] = (uint8_t)ok, ed[i] = ok ? conv : -1;

@@ -51,6 +51,41 @@ int ref_simd_ed_batch(int64_t n, const char* reads, const uint32_t* read_off, co
     return 0;
 }
 
+// The same driver with init_levenshtein's ED_modes argument (oracle numbering: 0 GLOBAL, 1 LOCAL, 2 SEMI_FREE_BEGIN,
+// 3 SEMI_FREE_END) and a caller-chosen warm-up pair (it must reach the end at a generation >= 1 in the mode at hand, so that
+// final_ED, final_lane_idx and converge_ED are all written before the batch starts).
+int ref_simd_ed_edmode_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,
+                             int ed_t, int shd_enable, int mode, const char* warm_read, const char* warm_ref, int32_t* ed,
+                             uint8_t* pass) {
+    static const ED_modes map[4] = {ED_GLOBAL, ED_LOCAL, ED_SEMI_FREE_BEGIN, ED_SEMI_FREE_END};
+    if (mode < 0 || mode > 3) return -1;
+    SIMD_ED* obj = new SIMD_ED;
+    obj->init_levenshtein(ed_t, map[mode], shd_enable != 0);
+    {
+        std::string a(warm_read), b(warm_ref);
+        obj->load_reads((char*)a.c_str(), (char*)b.c_str(), (int)a.size());
+        obj->calculate_masks();
+        obj->reset();
+        obj->run();
+    }
+    std::string s1, s2;
+    for (int64_t i = 0; i < n; i++) {
+        int m = (int)(read_off[i + 1] - read_off[i]);
+        int nn = (int)(ref_off[i + 1] - ref_off[i]);
+        s1.assign(reads + read_off[i], m);
+        s2.assign(refs + ref_off[i], nn);
+        int length = m > 256 ? 256 : m;
+        obj->load_reads((char*)s1.c_str(), (char*)s2.c_str(), length);
+        obj->calculate_masks();
+        obj->reset();
+        obj->run();
+        pass[i] = obj->check_pass() ? 1 : 0;
+        ed[i] = obj->get_ED();
+    }
+    delete obj;
+    return 0;
+}
+
 // Affine mode, CLEAN: init_affine before every pair (it destroys and rebuilds the tables: -2 everywhere, start[mid][0] = 0), so
 // that no pair sees the tables of the one before; ed[i] = get_ED(), pass[i] = check_pass().
 int ref_simd_ed_affine_shd_batch(int64_t n, const char* reads, const uint32_t* read_off, const char* refs, const uint32_t* ref_off,

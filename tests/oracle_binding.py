@@ -76,6 +76,7 @@ class Oracle:
         lib.orc_set_threads.argtypes = [_i]
         lib.orc_simd_ed_batch.argtypes = b5 + [_i] * 3 + [_vp] * 4
         lib.orc_shd_batch.argtypes = b5 + [_i, _vp]
+        lib.orc_simd_ed_edmode_batch.argtypes = b5 + [_i] * 4 + [_vp] * 4
         lib.orc_simd_ed_affine_batch.argtypes = b5 + [_i] * 5 + [_vp, _vp]
         lib.orc_simd_ed_affine_shd_batch.argtypes = b5 + [_i] * 7 + [_vp, _vp]
         lib.orc_simd_ed_affine_mode_batch.argtypes = b5 + [_i] * 8 + [_vp, _vp]
@@ -190,15 +191,16 @@ class Oracle:
         assert self.lib.orc_nw_cigar_batch(*args, x, o, e, pen.ctypes.data, cg.ctypes.data, CIGAR_STRIDE) == 0
         return pen, _cigars(cg, hb.n, CIGAR_STRIDE)
 
-    def simd_ed(self, hb, ed_t=3, shd=True, mode=0, state=SIMD_WARM_STATE):
-        """(ed, ed_raw, pass): ed = converge_ED when the pair passes else -1; ed_raw = get_ED() whatever the verdict."""
+    def simd_ed(self, hb, ed_t=3, shd=True, mode=0, state=SIMD_WARM_STATE, ed_mode=0):
+        """(ed, ed_raw, pass): ed = get_ED() when the pair passes else -1; ed_raw = get_ED() whatever the verdict.  ed_mode:
+        init_levenshtein's ED_modes in the oracle's numbering (0 GLOBAL, 1 LOCAL, 2 SEMI_FREE_BEGIN, 3 SEMI_FREE_END)."""
         keep, args = _batch_args(hb)
         ed = np.zeros(hb.n, np.int32)
         raw = np.zeros(hb.n, np.int32)
         ps = np.zeros(hb.n, np.uint8)
         st = np.array(state, np.int32)
-        rc = self.lib.orc_simd_ed_batch(*args, ed_t, 1 if shd else 0, mode, st.ctypes.data, ed.ctypes.data,
-                                        raw.ctypes.data, ps.ctypes.data)
+        rc = self.lib.orc_simd_ed_edmode_batch(*args, ed_t, 1 if shd else 0, mode, int(ed_mode), st.ctypes.data, ed.ctypes.data,
+                                               raw.ctypes.data, ps.ctypes.data)
         assert rc == 0, rc
         return ed, raw, ps
 
@@ -245,6 +247,7 @@ class ReferenceSimd:
         b5 = [_i64, _vp, _vp, _vp, _vp]
         lib.ref_simd_ed_batch.argtypes = b5 + [_i, _i, _vp, _vp]
         lib.ref_shd_batch.argtypes = b5 + [_i, _vp]
+        lib.ref_simd_ed_edmode_batch.argtypes = b5 + [_i] * 3 + [ctypes.c_char_p, ctypes.c_char_p, _vp, _vp]
         lib.ref_simd_ed_affine_batch.argtypes = b5 + [_i] * 5 + [_vp, _vp]
         lib.ref_simd_ed_affine_shd_batch.argtypes = b5 + [_i] * 7 + [_vp, _vp]
         lib.ref_simd_ed_affine_mode_batch.argtypes = b5 + [_i] * 8 + [_vp, _vp]
@@ -255,6 +258,15 @@ class ReferenceSimd:
         ed = np.zeros(hb.n, np.int32)
         ps = np.zeros(hb.n, np.uint8)
         assert self.lib.ref_simd_ed_batch(*args, ed_t, 1 if shd else 0, ed.ctypes.data, ps.ctypes.data) == 0
+        return ed, ps
+
+    def simd_ed_edmode(self, hb, ed_t, shd, ed_mode, warm=("ACGT", "ACTT")):
+        """(get_ED(), check_pass()) as run, one object, init_levenshtein(ed_t, ED_modes ed_mode, shd), after the warm-up pair."""
+        keep, args = _batch_args(hb)
+        ed = np.zeros(hb.n, np.int32)
+        ps = np.zeros(hb.n, np.uint8)
+        assert self.lib.ref_simd_ed_edmode_batch(*args, ed_t, 1 if shd else 0, int(ed_mode), warm[0].encode(), warm[1].encode(),
+                                                 ed.ctypes.data, ps.ctypes.data) == 0
         return ed, ps
 
     def simd_ed_affine(self, hb, gap_t=3, af_t=60, x=2, o=3, e=1, shd_t=None, mode=0):

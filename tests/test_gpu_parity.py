@@ -620,6 +620,25 @@ def test_simd_ed_affine_filter_ed_modes(asm, engine, oracle, wl, n, mode):
         engine.simd_ed_affine(batch, 3, 60, 2, 3, 1, mode=4)
 
 
+@pytest.mark.parametrize("ed_mode", [1, 2, 3])
+@pytest.mark.parametrize("wl,n", [("C2", 8000), ("C4", 6000), ("C5", 6000)])
+def test_simd_ed_levenshtein_ed_modes(asm, engine, oracle, wl, n, ed_mode):
+    """init_levenshtein's ED_modes (LOCAL / SEMI_FREE_BEGIN / SEMI_FREE_END): sequential (state carried, as the reference runs)
+    and clean, with and without SHD, register-sized and larger thresholds; the state a sequential call returns."""
+    from tests.oracle_binding import SIMD_WARM_STATE
+    cfg, _, _ = asm.workload(wl)
+    hb = asm.generate_pairs(cfg, 61, n)
+    batch = engine.upload(hb, asm.GREEDY_CLEAN)
+    for t, shd in ((3, True), (5, False), (12, True), (20, False)):
+        for fmode in (asm.FILTER_SEQUENTIAL, asm.FILTER_CLEAN):
+            want, _, _ = oracle.simd_ed(hb, t, shd, fmode, SIMD_WARM_STATE, ed_mode=ed_mode)
+            got = engine.simd_ed(batch, t, shd, fmode, SIMD_WARM_STATE, ed_mode=ed_mode)
+            bad = np.nonzero(got != want)[0]
+            assert bad.size == 0, (wl, ed_mode, t, shd, fmode, bad[:5], got[bad[:5]], want[bad[:5]])
+    with pytest.raises(asm.AsmError):
+        engine.simd_ed(batch, 3, True, asm.FILTER_CLEAN, None, ed_mode=7)
+
+
 def test_filters_ignore_the_stale_tails_of_sequential_batches(asm, engine, oracle):
     """A batch packed for Greedy's sequential mode keeps the reference's stale buffer tails beyond each string's end; NW, LEAP
     and the three filters must not see them (mixed lengths: long pairs leave long tails for the short ones that follow)."""

@@ -218,3 +218,36 @@ def test_simd_ed_affine_ed_modes_match_the_compiled_reference(asm, oracle, mode)
             assert np.array_equal(o_ed, np.where(r_ps == 1, r_ed, -1)), (mode, g, af, x, o, e, st)
             saw_exact |= bool(((o_ed == 0) | (o_ed == 1000000)).any())
     assert saw_exact
+
+
+@pytest.mark.skipif(not oracle_binding.have_reference_simd(), reason="oracle/_ref/libasm_ref_simd.so not built")
+@pytest.mark.parametrize("ed_mode", [1, 2, 3])
+def test_simd_ed_levenshtein_ed_modes_match_the_compiled_reference(asm, oracle, ed_mode):
+    """init_levenshtein's ED_modes argument (SIMD_ED.cpp:246-266,277-351,748-753), AS RUN: one object, a warm-up pair that
+    reaches the end at generation 1 (so final_ED, final_lane_idx and converge_ED are written), then the batch.  LOCAL and
+    SEMI_FREE_END read no state of earlier pairs; SEMI_FREE_BEGIN carries GLOBAL's stale-state rule (S2) — the oracle gets the
+    warm-up pair prepended and a zero state."""
+    ref = oracle_binding.load_reference_simd()
+    warm_read = "ACGTTGCAAGCTTAGGCATCGATCCGATTAGCATGCATGC"
+    warm_ref = warm_read[:20] + ("A" if warm_read[20] != "A" else "C") + warm_read[21:]
+    warm = (warm_read, warm_ref)
+
+    def with_warm(hb):
+        reads = np.concatenate([np.frombuffer(warm[0].encode(), np.uint8), hb.reads])
+        refs = np.concatenate([np.frombuffer(warm[1].encode(), np.uint8), hb.refs])
+        ro = np.concatenate([[0], hb.read_off.astype(np.int64) + len(warm[0])]).astype(np.uint32)
+        fo = np.concatenate([[0], hb.ref_off.astype(np.int64) + len(warm[1])]).astype(np.uint32)
+        return asm.HostBatch(reads, ro, refs, fo)
+
+    for wl, n in (("C2", 2500), ("C4", 2000), ("C5", 2000), ("C3", 800)):
+        hb = asm.generate_pairs(asm.workload(wl)[0], 43, n)
+        hw = with_warm(hb)
+        for t, shd in ((3, True), (5, False), (12, True), (20, False)):
+            o_ed, o_raw, o_ps = oracle.simd_ed(hw, t, shd, 0, (0, 0, 0), ed_mode=ed_mode)
+            assert o_ps[0] == 1 and o_raw[0] == 1, "the warm-up pair must reach the end at generation 1 on the main lane"
+            r_ed, r_ps = ref.simd_ed_edmode(hb, t, shd, ed_mode, warm)
+            assert np.array_equal(o_ps[1:], r_ps), (wl, t, shd, ed_mode)
+            assert np.array_equal(o_raw[1:][r_ps == 1], r_ed[r_ps == 1]), (wl, t, shd, ed_mode)
+            if ed_mode in (1, 3):  # order-independent: the clean form gives the same verdicts
+                c_ed, _, c_ps = oracle.simd_ed(hb, t, shd, 1, (0, 0, 0), ed_mode=ed_mode)
+                assert np.array_equal(c_ps, r_ps) and np.array_equal(c_ed, np.where(r_ps == 1, r_ed, -1))

@@ -60,6 +60,9 @@ while time.time() - t0 < budget:
         T = int(rng.integers(1, 21))
         want_l, _, _ = orc.simd_ed(hb, T, False, 1, (0, 0, 0))
         res.append(("simd_ed", bool(np.array_equal(eng.simd_ed(batch, T, False, m.FILTER_CLEAN), want_l))))
+        lm = int(rng.integers(1, 4)); fm = int(rng.integers(0, 2)); sh = bool(rng.integers(0, 2)) and T <= 16  # init_levenshtein's ED_modes
+        want_lm, _, _ = orc.simd_ed(hb, T, sh, fm, (1, 1, 2), ed_mode=lm)
+        res.append((f"simd_ed_m{lm}", bool(np.array_equal(eng.simd_ed(batch, T, sh, fm, (1, 1, 2), ed_mode=lm), want_lm))))
         g, af = int(rng.integers(1, 33)), int(rng.integers(1, 200))
         ax = int(rng.integers(1, 8)); ae = int(rng.integers(1, 5)); ao = ae + int(rng.integers(0, 6))
         want_a, _ = orc.simd_ed_affine(hb, g, af, ax, ao, ae)
