@@ -49,6 +49,8 @@ struct asm_handle {
     bool tail_set = false;
     hipEvent_t ev_out[2] = {nullptr, nullptr}; /* repack = 3: the counters of the call before last (same output arrays) are done */
     unsigned calls3 = 0;
+    const void* last3_out[3] = {nullptr, nullptr, nullptr}; /* the output arrays of the previous overlapped call (misuse guard) */
+    bool last3_valid = false;
     bool pipe_prev = false;               /* the previous asm_run_benchmark_async call was a pipelined one (repack 2 or 3) */
     hipEvent_t ev_gate = nullptr;         /* repack = 2: the next call's pack starts behind this point of the current call */
     bool gate_set = false;
@@ -813,6 +815,7 @@ int asm_pipeline_join_async(asm_handle* h) {
     HIPCHK(h, hipSetDevice(h->device));
     if (h->tail_set) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_tail, 0));
     h->pipe_prev = false; /* the next pipelined call starts behind this point of the caller's stream: any output set may follow */
+    h->last3_valid = false;
     return ASM_OK;
 }
 
@@ -1993,6 +1996,13 @@ int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, in
         pmask |= 1u << (q);                                                  \
     }
     hipStream_t main_stream = h->stream;
+    /* the contract of repack = 3: consecutive overlapped calls write different arrays (the previous call's counters may still be
+     * reading its own).  A caller that forgets is told so instead of getting a race. */
+    if (repack == 3 && h->last3_valid && ((d_nw && d_nw == h->last3_out[0]) || (d_leap && d_leap == h->last3_out[1]) ||
+                                          (d_greedy && d_greedy == h->last3_out[2])))
+        return fail(h, ASM_EINVAL, "asm_run_benchmark_async: repack = 3 needs output arrays that alternate between two sets (these "
+                                   "were the previous call's); asm_pipeline_join_async first to reuse them");
+    if (repack != 3) h->last3_valid = false;
     if (repack != 3 && h->tail_set) { /* earlier overlapped calls: everything of theirs before anything of this one */
         HIPCHK(h, hipSetDevice(h->device));
         HIPCHK(h, hipStreamWaitEvent(main_stream, h->ev_tail, 0));
@@ -2058,6 +2068,8 @@ int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, in
         PROF(3, 1, main_stream)
     }
     if (repack == 3 && pipelined && !greedy_first && !rc) {
+        h->last3_out[0] = d_nw, h->last3_out[1] = d_leap, h->last3_out[2] = d_greedy;
+        h->last3_valid = true;
         /* OVERLAPPED calls: nothing of this call waits for the previous call's Greedy, and the caller's stream is not joined
          * here (asm_pipeline_join_async does that).  Three chains run through consecutive calls — NW -> LEAP -> NW -> ... on the
          * caller's stream, Greedy -> Greedy on the side stream, pack -> pack on the pack stream — and each call's counters
@@ -2692,11 +2704,12 @@ int asm_stream_seq_file(asm_handle* h, const char* path, const asm_params* p, in
         STREAM_TRY(hipStreamWaitEvent(h->stream, ev_h2d[q], 0));
         asm_batch* b = nullptr;
         const auto tp0 = std::chrono::steady_clock::now();
-        if (getenv("ASM_STREAM_DEBUG")) (void)hipEventSynchronize(ev_h2d[q]);
+        static const bool stream_debug = getenv("ASM_STREAM_DEBUG") != nullptr; /* development: per-chunk timings on stderr */
+        if (stream_debug) (void)hipEventSynchronize(ev_h2d[q]);
         const auto tp1 = std::chrono::steady_clock::now();
         if (!rc) rc = batch_from_device_text(h, d_raw[q], shipped, n, ASM_GREEDY_CLEAN, &b);
         const auto tp2 = std::chrono::steady_clock::now();
-        if (getenv("ASM_STREAM_DEBUG"))
+        if (stream_debug)
             fprintf(stderr, "chunk %ld pairs: wait h2d %.3f ms, parse+pack %.3f ms\n", (long)n,
                     std::chrono::duration<double, std::milli>(tp1 - tp0).count(), std::chrono::duration<double, std::milli>(tp2 - tp1).count());
         if (rc) return;

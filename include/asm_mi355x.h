@@ -302,7 +302,8 @@ int asm_accuracy_async(asm_handle* h, const int32_t* d_nw, const int32_t* d_leap
  * outputs and counters of all calls so far are complete on it after asm_pipeline_join_async (asm_synchronize also waits for
  * them).  The caller ALTERNATES between two sets of output arrays from call to call (a set is written again two calls later,
  * when the library has seen its counters finish), and calls asm_pipeline_join_async before it touches the batch or the outputs
- * in any other way.  A later call with repack != 3 joins by itself. */
+ * in any other way.  A later call with repack != 3 joins by itself.  Passing the previous overlapped call's arrays again without a
+ * join in between is refused (ASM_EINVAL). */
 int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, int repack, int32_t* d_nw,
                             int32_t* d_leap, int32_t* d_greedy, const int32_t* d_answers,
                             unsigned long long* d_counters);
