@@ -1721,28 +1721,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void accuracy_kernel(const int32_t* __re
     const int4* leap4 = reinterpret_cast<const int4*>(leap);
     const int4* greedy4 = reinterpret_cast<const int4*>(greedy);
     const int4* ans4 = reinterpret_cast<const int4*>(answers);
-    long q = i;
-    if (answers == nullptr) {
-        // the usual case (the correct answer is the NW penalty): four iterations' loads issued before the first compare, so that
-        // a thread has up to twelve 16-byte loads in flight — with 128 workgroups the plain loop is latency-bound (13 us at 10^6)
-        const int4 zero = make_int4(0, 0, 0, 0);
-        for (; q + 3 * stride < n4; q += 4 * stride) {
-            int4 p[4], l[4], g[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) p[u] = nw4[q + u * stride];
-#pragma unroll
-            for (int u = 0; u < 4; u++) l[u] = leap != nullptr ? leap4[q + u * stride] : zero;
-#pragma unroll
-            for (int u = 0; u < 4; u++) g[u] = greedy != nullptr ? greedy4[q + u * stride] : zero;
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                c_nw += 4;
-                c_leap += (l[u].x == p[u].x) + (l[u].y == p[u].y) + (l[u].z == p[u].z) + (l[u].w == p[u].w);
-                c_greedy += (g[u].x == p[u].x) + (g[u].y == p[u].y) + (g[u].z == p[u].z) + (g[u].w == p[u].w);
-            }
-        }
-    }
-    for (; q < n4; q += stride) {
+    for (long q = i; q < n4; q += stride) {
         const int4 p = nw4[q];
         int4 want = p;
         if (answers != nullptr) {
