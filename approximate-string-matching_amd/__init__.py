@@ -147,6 +147,7 @@ def load_library() -> ctypes.CDLL:
         "asm_batch_resolve_tails": (i32, [vp, vp, vp]),
         "asm_batch_size": (i64, [vp]),
         "asm_batch_max_length": (i32, [vp]),
+        "asm_batch_text_bytes": (i64, [vp]),
         "asm_batch_download": (i32, [vp, vp, vp, vp, vp, c.c_size_t, vp, c.c_size_t]),
         "asm_batch_pack_async": (i32, [vp, vp]),
         "asm_align_batch_async": (i32, [vp, vp, i32, c.POINTER(Params), vp]),
@@ -276,6 +277,7 @@ class DeviceBatch:
         self.engine, self.ptr = engine, ptr
         self.n = int(engine.lib.asm_batch_size(ptr))
         self.max_length = int(engine.lib.asm_batch_max_length(ptr))
+        self.ascii_bytes = int(engine.lib.asm_batch_text_bytes(ptr))
 
     def free(self) -> None:
         if self.ptr:

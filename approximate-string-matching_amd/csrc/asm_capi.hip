@@ -25,7 +25,6 @@
 #include "../../include/asm_mi355x.h"
 #include "asm_kernels.h"
 #include "asm_greedy3_kernel.h"
-#include "asm_greedy_prune_kernel.h"
 #include "asm_wide.h"
 #include "asm_wave.h"
 #include "asm_group.h"
@@ -35,6 +34,8 @@
 #include "asm_ingest.h"
 
 struct asm_handle {
+    unsigned long long serial = 0;        /* unique over the life of the process: a batch names its owner by (pointer, serial), so a
+                                             new handle that happens to get a destroyed one's address is not taken for it */
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -43,7 +44,6 @@ struct asm_handle {
     hipStream_t pack_stream = nullptr;    /* ... and, with repack = 2, packs for this call while the previous call still aligns */
     hipEvent_t ev_packed = nullptr;
     hipEvent_t ev_nw = nullptr;
-    int leap_own = 1;                     /* repack = 3: LEAP runs on acc_stream, behind the NW of its call and beside the NW of the next (ASM_LEAP_STREAM=0: behind NW on the caller's stream) */
     hipStream_t acc_stream = nullptr;     /* repack = 3: the counters of a call, behind both of its chains */
     hipEvent_t ev_leap = nullptr, ev_tail = nullptr;
     bool tail_set = false;
@@ -54,42 +54,29 @@ struct asm_handle {
     bool pipe_prev = false;               /* the previous asm_run_benchmark_async call was a pipelined one (repack 2 or 3) */
     hipEvent_t ev_gate = nullptr;         /* repack = 2: the next call's pack starts behind this point of the current call */
     bool gate_set = false;
-    int simd_quad_min = 1;                /* SIMD_ED affine, strings <= 128: four threads per pair from this gap threshold on (ASM_SIMD_QUAD; 0.29/0.46/0.79 ms per 10^6 C2 pairs at gap 3/8/30 with (2,3,1), thread per pair 0.28/0.71/3.5) */
-    int pack_gate = -1;                   /* 0 none, 1 behind NW, 2 behind LEAP; -1 = 1 with repack 2, 0 with repack 3 (ASM_PACK_GATE) */
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_switch = nullptr;
     bool overlap = true;                  /* ASM_OVERLAP=0: everything on one stream */
     std::string err;
     int num_cus = 256;
-    bool persist = true;                  /* Greedy: lane-refilling persistent kernel (ASM_PERSIST=0 disables) */
-    bool persist_leap = false;            /* LEAP: the plain one-pair-per-thread kernel is faster at 1e6 pairs (ASM_PERSIST_LEAP=1) */
-    int refill_greedy = 8, refill_leap = 16; /* lanes that must be idle before a wave refills (tunable by env) */
-    int greedy_prune = 0;                 /* Greedy, unit penalties, GLOBAL: band half-widths from this one up to 31 run the exactly-pruned
-                                             thread-per-pair kernel (asm_greedy_prune.h).  OFF by default (0): bit-identical, but measured
-                                             2.8x SLOWER than the wave-per-pair kernel at C3 — a wave pays for its unluckiest thread
-                                             (DESIGN.md section 7).  ASM_GREEDY_PRUNE=<k> switches it on from k up */
-    int prune_waves = 8;                  /* its waves per CU (ASM_PRUNE_WAVES: 4, 8, 12, 16; LDS holds 160 B per thread) */
-    int g3_park = 0;                      /* ASM_GREEDY_PARK: drain compaction of the fast Greedy kernel (asm_greedy3_kernel.h) */
-    int g3_waves = 2;                     /* resident waves per SIMD of the fast Greedy kernel (ASM_GREEDY_WAVES = 1, 2, 3) */
-    int persist_waves = 0;                /* cap on the resident waves per SIMD of the persistent kernels (ASM_PERSIST_WAVES; 0 = what fits) */
+    int refill_greedy = 8;                /* idle lanes a wave of the persistent Greedy kernels collects before it refills (1 … 32 measured: flat) */
     bool greedy_fast = true;              /* Greedy, k <= 3, unit penalties, GLOBAL: the straight-line pass with integer rank keys
                                              (asm_greedy3.h; ASM_GREEDY_FAST=0: the FP64 kernel) */
-    uint2* d_g3_table = nullptr;          /* its rank table (66 KB), built for g3_sig / g3_k; rebuilt when the probabilities change */
-    G3Sig g3_sig = {0.0, 0.0, 0.0};
-    int g3_k = 0;
-    bool g3_ok = false;
-    bool g3_attr[4] = {false, false, false, false};
+    /* its rank tables (66 KB each), one per (significance constants, K) seen so far.  A table is written once, before its first
+     * kernel, and never again — a call with other parameters gets another table, so kernels of earlier, still running calls on
+     * other streams keep reading theirs.  The newest is tried first. */
+    struct G3Table {
+        G3Sig sig;
+        int k;
+        bool ok;
+        uint2* d;
+    };
+    std::vector<G3Table> g3_tables;
+    const uint2* d_g3_table = nullptr;    /* the table of the current call (set by g3_prepare) */
     bool leap_hint = true;                /* LEAP scheduled by a work hint when one is given (ASM_LEAP_HINT=0 disables) */
     bool bucketing = true;                /* group mixed-length batches by width class (ASM_BUCKET=0 disables) */
     bool wave_kernels = true;             /* wave-per-pair kernels for 6 <= k <= 31 (ASM_WAVE=0: workgroup-per-pair LDS kernels) */
-    bool persist_wide = true;             /* Greedy, k = 6..16: still one thread per pair — up to 29 lane vectors in 512 VGPR+AGPR, one
-                                             wave per SIMD (ASM_PERSIST_WIDE=0: wave per pair) */
-    bool group_kernels = true;            /* Greedy, 32 <= k <= 39: sixteen threads per pair (ASM_GROUP=0: two wavefronts per pair) */
     bool nw_bylen = true;                 /* unit-cost NW on mixed-length batches: workgroup-local sort by length (ASM_NW_BYLEN=0) */
     bool nw_banded = true;                /* banded bit-parallel NW with in-kernel full-height recompute (ASM_NW_BANDED=0) */
-    int leap_quad = 3;                    /* LEAP, wide band: four threads per pair (ASM_LEAP_QUAD bit 0: unit penalties, bit 1: general) */
-    bool leap_band = true;                /* LEAP, wide band: thread per pair with the band in LDS (ASM_LEAP_BAND=0: wave per pair) */
-    int ring_bytes = -1;                  /* thread-per-pair generation rings as bytes: -1 = where it pays, 0 / 1 force (ASM_RING_BYTES) */
-    int nw_wfa_second = 1;                /* affine NW: second wavefront pass with the wider band — 1: eight threads per pair, 2: thread per pair, 0: straight to the full matrix (ASM_NW_WFA2) */
     bool nw_wfa = true;                   /* affine NW: banded wavefront first, full matrix for the rest (ASM_NW_WFA=0: full matrix only) */
     std::vector<hipEvent_t> prof_ev;      /* asm_profile_enable: 8 events per recorded asm_run_benchmark_async call */
     std::vector<unsigned> prof_mask;      /* which of a call's four kernels were launched */
@@ -195,6 +182,7 @@ struct asm_bucket {
 
 struct asm_batch {
     asm_handle* owner = nullptr; /* whose pool the device blocks come from */
+    unsigned long long owner_serial = 0;
     int64_t n = 0;
     int maxlen = 0;
     int greedy_mode = ASM_GREEDY_CLEAN;
@@ -233,10 +221,11 @@ static thread_local std::string g_err;
  * handle, or after its own is gone */
 static std::mutex g_live_mu;
 static std::vector<asm_handle*> g_live_handles;
-static bool handle_is_live(asm_handle* h) {
-    std::lock_guard<std::mutex> lk(g_live_mu);
+static unsigned long long g_next_serial = 1; /* under g_live_mu */
+/* call with g_live_mu held: is the handle that created a batch still the one living at that address? */
+static bool owner_is_live_locked(const asm_handle* h, unsigned long long serial) {
     for (asm_handle* q : g_live_handles)
-        if (q == h) return true;
+        if (q == h) return q->serial == serial;
     return false;
 }
 
@@ -264,7 +253,6 @@ static hipError_t launch_persistent(asm_handle* h, Kern kern, int64_t n, Args...
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, ASM_BLOCK, 0);
     if (e != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
-    if (h->persist_waves > 0 && per_cu > h->persist_waves) per_cu = h->persist_waves; /* a 256-thread workgroup is one wave per SIMD */
     int64_t blocks = (int64_t)per_cu * h->num_cus;
     const int64_t need = (n + ASM_BLOCK - 1) / ASM_BLOCK;
     if (blocks > need) blocks = need;
@@ -281,27 +269,44 @@ extern "C" void asm_diag_set_buffer(void* d) { g_diag_buf = d; }
  * the integer keys need (then the FP64 kernel runs). */
 static bool g3_prepare(asm_handle* h, const GreedyArgs& ga, int K) {
     const G3Sig sig = {ga.sig_match, ga.sig_mismatch, ga.sig_indel};
-    if (h->g3_k == K && memcmp(&sig, &h->g3_sig, sizeof(sig)) == 0) return h->g3_ok;
-    h->g3_k = K, h->g3_sig = sig, h->g3_ok = false;
+    for (size_t q = h->g3_tables.size(); q-- > 0;) {
+        const asm_handle::G3Table& t = h->g3_tables[q];
+        if (t.k == K && memcmp(&sig, &t.sig, sizeof(sig)) == 0) {
+            h->d_g3_table = t.d;
+            return t.ok;
+        }
+    }
+    /* a new parameter set: builds the table on the host and BLOCKS until it is on the device (once per parameter set) */
+    asm_handle::G3Table t = {sig, K, false, nullptr};
     std::vector<uint2> tab;
-    if (!g3_build_table(sig, K, tab)) return false;
-    if (!h->d_g3_table && big_malloc(h, (void**)&h->d_g3_table, sizeof(uint2) * G3_TABLE_ENTRIES) != hipSuccess) {
-        (void)hipGetLastError();
-        h->d_g3_table = nullptr;
-        return false;
+    if (g3_build_table(sig, K, tab)) {
+        if (h->g3_tables.size() >= 16) { /* a caller cycling through parameter sets: drop the oldest, after everything has drained */
+            (void)hipDeviceSynchronize();
+            if (h->g3_tables.front().d) (void)hipFree(h->g3_tables.front().d);
+            h->g3_tables.erase(h->g3_tables.begin());
+        }
+        if (big_malloc(h, (void**)&t.d, sizeof(uint2) * G3_TABLE_ENTRIES) == hipSuccess &&
+            hipMemcpyAsync(t.d, tab.data(), sizeof(uint2) * G3_TABLE_ENTRIES, hipMemcpyHostToDevice, h->stream) == hipSuccess &&
+            hipStreamSynchronize(h->stream) == hipSuccess) { /* pageable source: staged before the call returns */
+            t.ok = true;
+        } else {
+            (void)hipGetLastError();
+            if (t.d) (void)hipFree(t.d);
+            t.d = nullptr;
+        }
     }
-    /* pageable source: the copy is staged before the call returns; ordered on the stream the kernels run on */
-    if (hipMemcpyAsync(h->d_g3_table, tab.data(), sizeof(uint2) * G3_TABLE_ENTRIES, hipMemcpyHostToDevice, h->stream) != hipSuccess) {
-        (void)hipGetLastError();
-        return false;
-    }
-    if (hipStreamSynchronize(h->stream) != hipSuccess) return false;
-    h->g3_ok = true;
-    return true;
+    h->g3_tables.push_back(t);
+    h->d_g3_table = t.d;
+    return t.ok;
 }
 
-template <int K, int NT>
-static hipError_t launch_greedy_fast_nt(asm_handle* h, const asm_bucket& b, const GreedyArgs& ga, OutMap out, CigarSink cig) {
+template <int K>
+static hipError_t launch_greedy_fast(asm_handle* h, const asm_bucket& b, const GreedyArgs& ga, OutMap out, CigarSink cig) {
+    /* One 512-thread workgroup per CU = two waves per SIMD.  The waves of a SIMD are served oldest first and this kernel is a
+     * dense stream of 4-cycle vector operations, so a third wave adds little issue rate and a third more lanes to drain at the
+     * end: stand-alone 1 / 2 / 3 waves take 130 / 118 / 107 us, inside asm_run_benchmark_async's overlapped step 0.234 / 0.227 /
+     * 0.244 ms per step (1.5 and 2.5 waves: 0.237, —).  The other instantiations were removed in round 4 (last in 312851a). */
+    constexpr int NT = G3_THREADS;
     auto kern = greedy_fast_kernel<K, NT>;
     const size_t lds = g3_lds_bytes(K, NT);
     { /* more than 64 KB of dynamic LDS has to be asked for */
@@ -313,107 +318,28 @@ static hipError_t launch_greedy_fast_nt(asm_handle* h, const asm_bucket& b, cons
     if (blocks > need) blocks = need;
     const G3Sig sig = {ga.sig_match, ga.sig_mismatch, ga.sig_indel};
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NT), lds, h->stream, (const uint4*)b.planes, (const uint32_t*)b.lens,
-                       (long)b.n, b.w4, sig, (const uint2*)h->d_g3_table, out, cig, h->refill_greedy, h->g3_park);
+                       (long)b.n, b.w4, sig, h->d_g3_table, out, cig, h->refill_greedy);
     return hipGetLastError();
 }
-template <int K>
-static hipError_t launch_greedy_fast(asm_handle* h, const asm_bucket& b, const GreedyArgs& ga, OutMap out, CigarSink cig) {
-    /* waves per SIMD: the waves of a SIMD are served oldest first and this kernel is a dense stream of 4-cycle vector
-     * operations, so a third wave adds little issue rate and a third more lanes to drain at the end; two is the optimum both
-     * alone (118 us against 130) and beside NW -> LEAP in asm_run_benchmark_async */
-    if (h->g3_waves == 1) return launch_greedy_fast_nt<K, 256>(h, b, ga, out, cig);
-    if (h->g3_waves == 3) return launch_greedy_fast_nt<K, 768>(h, b, ga, out, cig);
-    if (h->g3_waves == 15) return launch_greedy_fast_nt<K, 384>(h, b, ga, out, cig); /* 1.5: six waves per CU */
-    if (h->g3_waves == 25) return launch_greedy_fast_nt<K, 640>(h, b, ga, out, cig); /* 2.5: ten waves per CU */
-    return launch_greedy_fast_nt<K, 512>(h, b, ga, out, cig);
-}
 
-/* Wide band, unit penalties, GLOBAL: set-up (wave per pair: per-lane constants), the pruned thread-per-pair kernel, and the
- * wave-per-pair kernel over the pairs that outran the pruned kernel's pass history (asm_greedy_prune.h). */
-static int launch_greedy_pruned(asm_handle* h, const asm_bucket& b, int k, const GreedyArgs& ga, OutMap out, CigarSink cig) {
-    signed char* d_info = nullptr; /* zl of every band lane: 64 bytes per pair */
-    PrPairInfo* d_zl = nullptr;    /* the set-up kernel's per-pair summaries */
-    uint32_t* d_todo = nullptr; /* [0] = count, [1..] = pair slots */
-    int rc = ASM_OK;
-    do {
-#define TRY(call)                                                        \
-    if ((call) != hipSuccess) {                                          \
-        rc = fail(h, ASM_ENODEVICE, std::string(#call) + " failed");     \
-        break;                                                           \
-    }
-        TRY(pool_alloc(h, (void**)&d_info, 64 * (size_t)b.n + 16));
-        TRY(pool_alloc(h, (void**)&d_zl, sizeof(PrPairInfo) * (size_t)b.n));
-        TRY(pool_alloc(h, (void**)&d_todo, sizeof(uint32_t) * ((size_t)b.n + 1)));
-        TRY(hipMemsetAsync(d_todo, 0, sizeof(uint32_t), h->stream));
-        {
-            int64_t blocks = (int64_t)h->num_cus * 8; /* wave per pair, striding */
-            const int64_t need = (b.n + 3) / 4;
-            if (blocks > need) blocks = need;
-            hipLaunchKernelGGL(prune_setup_kernel, dim3((unsigned)blocks), dim3(ASM_BLOCK), 0, h->stream, (const uint4*)b.planes,
-                               (const uint32_t*)b.lens, (long)b.n, b.w4, k, d_info, d_zl);
-            TRY(hipGetLastError());
-        }
-        {
-            auto kern_args_k = k;
-            (void)kern_args_k;
-            hipError_t e;
-            const G3Sig sig = {ga.sig_match, ga.sig_mismatch, ga.sig_indel};
-#define PRUNE_LAUNCH(NT)                                                                                                      \
-    {                                                                                                                         \
-        auto kern = greedy_prune_kernel<NT>;                                                                                  \
-        const size_t lds = pr_lds_bytes(NT);                                                                                  \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
-        if (e == hipSuccess) {                                                                                                \
-            int64_t blocks = h->num_cus;                                                                                      \
-            const int64_t need = (b.n + NT - 1) / NT;                                                                         \
-            if (blocks > need) blocks = need;                                                                                 \
-            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NT), lds, h->stream, (const uint4*)b.planes,                \
-                               (const uint32_t*)b.lens, (long)b.n, b.w4, k, sig, (const signed char*)d_info,                  \
-                               (const PrPairInfo*)d_zl, out, cig, h->refill_greedy, d_todo + 1, d_todo);                      \
-            e = hipGetLastError();                                                                                            \
-        }                                                                                                                     \
-    }
-            switch (h->prune_waves) {
-                case 4: PRUNE_LAUNCH(256) break;
-                case 12: PRUNE_LAUNCH(768) break;
-                case 16: PRUNE_LAUNCH(1024) break;
-                default: PRUNE_LAUNCH(512) break;
-            }
-#undef PRUNE_LAUNCH
-            TRY(e);
-        }
-        /* the pairs the pruned kernel handed back (more passes than its history holds): a fixed small grid walks the list */
-        TRY(hipMemsetAsync(h->d_pair_queue, 0, sizeof(unsigned long long), h->stream));
-        hipLaunchKernelGGL(greedy_wave_kernel<true>, dim3((unsigned)h->num_cus), dim3(ASM_BLOCK), 0, h->stream, (const uint4*)b.planes,
-                           (const uint32_t*)b.lens, (long)b.n, b.w4, k, ga, out, cig, h->d_pair_queue, (const uint32_t*)(d_todo + 1),
-                           (const uint32_t*)d_todo);
-        TRY(hipGetLastError());
-#undef TRY
-    } while (0);
-    pool_free(h, d_info), pool_free(h, d_zl), pool_free(h, d_todo); /* recycled in stream order */
-    return rc;
-}
-
+/* Thread-per-pair Greedy, k <= 16: the straight-line integer-key kernel for the benchmark's own configuration (k <= 3, unit
+ * penalties, GLOBAL), the FP64 lane-refilling kernel for everything else.  General penalties are compiled up to k = 5; wider
+ * bands with general penalties take the wave-per-pair kernel. */
 template <int K>
 static hipError_t launch_greedy(asm_handle* h, const asm_bucket& b, const GreedyArgs& ga, OutMap out, CigarSink cig) {
 #ifdef GREEDY_DIAG
     if (cig.ops == nullptr && g_diag_buf) cig.nops = (uint8_t*)g_diag_buf;
 #endif
+    const bool unit = ga.x == 1 && ga.o == 1 && ga.e == 1 && !ga.semi;
     if constexpr (K <= 3) {
-        if (h->greedy_fast && h->persist && ga.x == 1 && ga.o == 1 && ga.e == 1 && !ga.semi && g3_prepare(h, ga, K))
-            return launch_greedy_fast<K>(h, b, ga, out, cig);
+        if (h->greedy_fast && unit && g3_prepare(h, ga, K)) return launch_greedy_fast<K>(h, b, ga, out, cig);
     }
-    if (h->persist && ga.x == 1 && ga.o == 1 && ga.e == 1 && !ga.semi)
+    if (unit)
         return launch_persistent(h, greedy_persist_kernel<K, true>, b.n, (const uint4*)b.planes, (const uint32_t*)b.lens,
                                  (long)b.n, b.w4, ga, out, cig, h->refill_greedy);
-    if (h->persist)
+    if constexpr (K <= 5)
         return launch_persistent(h, greedy_persist_kernel<K, false>, b.n, (const uint4*)b.planes, (const uint32_t*)b.lens,
                                  (long)b.n, b.w4, ga, out, cig, h->refill_greedy);
-    if constexpr (K <= 5) { /* the one-pair-per-thread A/B form (ASM_PERSIST=0) exists for the narrow bands only */
-        hipLaunchKernelGGL(greedy_kernel<K>, dim3(grid_for(b.n)), dim3(ASM_BLOCK), 0, h->stream, b.planes, b.lens, (long)b.n,
-                           b.w4, ga, out, cig);
-        return hipGetLastError();
-    }
     return hipErrorInvalidValue;
 }
 
@@ -425,9 +351,6 @@ static hipError_t launch_leap_unit_w(asm_handle* h, const asm_bucket& b, OutMap 
                            (long)b.n, b.w4, out, hint);
         return hipGetLastError();
     }
-    if (h->persist_leap)
-        return launch_persistent(h, leap_unit_persist_kernel<K, W64>, b.n, (const uint4*)b.planes, (const uint32_t*)b.lens,
-                                 (long)b.n, b.w4, out, h->refill_leap);
     hipLaunchKernelGGL((leap_unit_kernel<K, W64>), dim3(grid_for(b.n)), dim3(ASM_BLOCK), 0, h->stream, b.planes, b.lens,
                        (long)b.n, b.w4, out);
     return hipGetLastError();
@@ -439,7 +362,7 @@ static hipError_t launch_leap_general_w(asm_handle* h, const asm_bucket& b, cons
     const RingGeometry rg(p->x, p->o, p->e);
     /* bytes (every stored position + 2 fits) halve the LDS and double the waves per CU, but four threads then write into one
      * dword: worth it only where shorts would leave the CU underfilled */
-    const bool bytes = b.maxlen + 4 <= 255 && (h->ring_bytes < 0 ? rg.lds_bytes(2 * K + 1, LEAP_GEN_THREADS, 2) > 20 * 1024 : h->ring_bytes != 0);
+    const bool bytes = b.maxlen + 4 <= 255 && rg.lds_bytes(2 * K + 1, LEAP_GEN_THREADS, 2) > 20 * 1024;
     if (bytes)
         hipLaunchKernelGGL((leap_general_kernel<K, W64, uint8_t>), grid, block, rg.lds_bytes(2 * K + 1, LEAP_GEN_THREADS, 1), h->stream,
                            b.planes, b.lens, (long)b.n, b.w4, (int)p->x, (int)p->o, (int)p->e, rg.gm, rg.gi, out);
@@ -451,12 +374,12 @@ static hipError_t launch_leap_general_w(asm_handle* h, const asm_bucket& b, cons
 
 /* Affine NW: banded wavefront pass (|d| <= 7), a second one with |d| <= 15 over the pairs the first could not settle
  * (strings up to 128 only), then the full-matrix kernel over what is left.  Two todo lists of n + 1 words each. */
-template <int K, int W64, typename EnT, bool LISTED>
+template <int K, int W64, typename EnT>
 static void launch_nw_wfa_pass(asm_handle* h, const asm_bucket& b, const asm_params* p, OutMap out, const uint32_t* in_list,
                                const uint32_t* in_count, uint32_t* todo, uint32_t* todo_count) {
     const WfaRings rg(p->x, p->o, p->e);
     const dim3 grid((unsigned)((b.n + LEAP_GEN_THREADS - 1) / LEAP_GEN_THREADS)), block(LEAP_GEN_THREADS);
-    hipLaunchKernelGGL((nw_wfa_kernel<K, W64, EnT, LISTED>), grid, block, rg.lds_bytes(2 * K + 1, LEAP_GEN_THREADS, sizeof(EnT)),
+    hipLaunchKernelGGL((nw_wfa_kernel<K, W64, EnT, false>), grid, block, rg.lds_bytes(2 * K + 1, LEAP_GEN_THREADS, sizeof(EnT)),
                        h->stream, b.planes, b.lens, (long)b.n, b.w4, (int)p->x, (int)p->o, (int)p->e, rg.gm, rg.gi, out, in_list,
                        in_count, todo, todo_count);
 }
@@ -477,13 +400,13 @@ static int launch_nw_wfa(asm_handle* h, const asm_bucket& b, const asm_params* p
     const WfaRings rg(p->x, p->o, p->e);
     bool bytes = false; /* strings up to 128: every stored position + 2 fits a byte, half the LDS */
     if constexpr (W64 == 2) {
-        bytes = h->ring_bytes != 0;
-        if (bytes) launch_nw_wfa_pass<NW_WFA_K, 2, uint8_t, false>(h, b, p, out, nullptr, nullptr, list_a + 1, list_a);
+        bytes = true;
+        launch_nw_wfa_pass<NW_WFA_K, 2, uint8_t>(h, b, p, out, nullptr, nullptr, list_a + 1, list_a);
     }
-    if (!bytes) launch_nw_wfa_pass<NW_WFA_K, W64, uint16_t, false>(h, b, p, out, nullptr, nullptr, list_a + 1, list_a);
+    if (!bytes) launch_nw_wfa_pass<NW_WFA_K, W64, uint16_t>(h, b, p, out, nullptr, nullptr, list_a + 1, list_a);
     const uint32_t* rest = list_a;
     const size_t en = b.maxlen + 2 <= 255 ? 1 : 2;
-    if (h->nw_wfa_second == 1 && nw_oct_lds(2 * W64, NW_WFA_K2, rg.gm, rg.gi, en) <= 64 * 1024) {
+    if (nw_oct_lds(2 * W64, NW_WFA_K2, rg.gm, rg.gi, en) <= 64 * 1024) {
         /* the unsettled percent or two: eight threads per pair, |d| <= 15 (asm_wave.h) */
         const dim3 grid((unsigned)std::min<int64_t>((b.n + NW_OCT_PAIRS - 1) / NW_OCT_PAIRS, (int64_t)h->num_cus * 16));
         if (en == 1)
@@ -495,11 +418,6 @@ static int launch_nw_wfa(asm_handle* h, const asm_bucket& b, const asm_params* p
                                h->stream, b.planes, b.lens, (long)b.n, b.w4, NW_WFA_K2, (int)p->x, (int)p->o, (int)p->e, rg.gm, rg.gi, out,
                                (const uint32_t*)(list_a + 1), (const uint32_t*)list_a, list_b + 1, list_b);
         rest = list_b;
-    } else if constexpr (W64 == 2) {
-        if (h->nw_wfa_second == 2 && rg.lds_bytes(2 * NW_WFA_K2 + 1, LEAP_GEN_THREADS, 1) <= 64 * 1024) { /* A/B: thread per pair */
-            launch_nw_wfa_pass<NW_WFA_K2, 2, uint8_t, true>(h, b, p, out, list_a + 1, list_a, list_b + 1, list_b);
-            rest = list_b;
-        }
     }
     hipLaunchKernelGGL((nw_affine_kernel<W64, MAXROWS>), dim3((unsigned)((b.n + 63) / 64)), dim3(64), 0, h->stream, b.planes,
                        b.lens, (long)b.n, b.w4, (int)p->x, (int)p->o, (int)p->e, out, rest + 1, rest);
@@ -674,59 +592,36 @@ int asm_create(asm_handle** out, int device) {
     h->stream = h->own_stream;
     HIPCHK(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
     HIPCHK(h, hipMalloc((void**)&h->d_pair_queue, sizeof(unsigned long long)));
-    {
-        const char* pp = getenv("ASM_PACK_PRIO");
-        int lo = 0, hi = 0;
-        if (pp && atoi(pp) != 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess)
-            HIPCHK(h, hipStreamCreateWithPriority(&h->pack_stream, hipStreamNonBlocking, atoi(pp) > 0 ? lo : hi));
-        else
-            HIPCHK(h, hipStreamCreateWithFlags(&h->pack_stream, hipStreamNonBlocking));
-        const char* sq = getenv("ASM_SIMD_QUAD");
-        if (sq) h->simd_quad_min = atoi(sq);
-        const char* pg = getenv("ASM_PACK_GATE");
-        if (pg) h->pack_gate = atoi(pg);
-    }
+    HIPCHK(h, hipStreamCreateWithFlags(&h->pack_stream, hipStreamNonBlocking));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_packed, hipEventDisableTiming));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_gate, hipEventDisableTiming));
     HIPCHK(h, hipStreamCreateWithFlags(&h->acc_stream, hipStreamNonBlocking));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_nw, hipEventDisableTiming));
-    if (getenv("ASM_LEAP_STREAM")) h->leap_own = atoi(getenv("ASM_LEAP_STREAM"));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_leap, hipEventDisableTiming));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_tail, hipEventDisableTiming));
     for (hipEvent_t& ev : h->ev_out) HIPCHK(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_switch, hipEventDisableTiming));
     hipDeviceProp_t prop;
     HIPCHK(h, hipGetDeviceProperties(&prop, device));
     h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    const char* env = getenv("ASM_PERSIST");
-    h->persist = !(env && env[0] == '0');
-    if ((env = getenv("ASM_PERSIST_LEAP"))) h->persist_leap = env[0] != '0';
-    if ((env = getenv("ASM_OVERLAP"))) h->overlap = env[0] != '0';
-    if ((env = getenv("ASM_LEAP_HINT"))) h->leap_hint = env[0] != '0';
-    if ((env = getenv("ASM_BUCKET"))) h->bucketing = env[0] != '0';
-    if ((env = getenv("ASM_WAVE"))) h->wave_kernels = env[0] != '0';
-    if ((env = getenv("ASM_GROUP"))) h->group_kernels = env[0] != '0';
-    if ((env = getenv("ASM_POOL"))) h->pooling = env[0] != '0';
-    if ((env = getenv("ASM_PERSIST_WIDE"))) h->persist_wide = env[0] != '0';
-    if ((env = getenv("ASM_NW_BANDED"))) h->nw_banded = env[0] != '0';
-    if ((env = getenv("ASM_NW_BYLEN"))) h->nw_bylen = env[0] != '0';
-    if ((env = getenv("ASM_NW_WFA"))) h->nw_wfa = env[0] != '0';
-    if ((env = getenv("ASM_NW_WFA2"))) h->nw_wfa_second = atoi(env);
-    if ((env = getenv("ASM_RING_BYTES"))) h->ring_bytes = atoi(env);
-    if ((env = getenv("ASM_LEAP_BAND"))) h->leap_band = env[0] != '0';
-    if ((env = getenv("ASM_LEAP_QUAD"))) h->leap_quad = atoi(env);
-    if ((env = getenv("ASM_LEAP_SORT"))) h->leap_sort = env[0] != '0';
-    if ((env = getenv("ASM_REFILL_GREEDY"))) h->refill_greedy = atoi(env);
-    if ((env = getenv("ASM_GREEDY_FAST"))) h->greedy_fast = env[0] != '0';
-    if ((env = getenv("ASM_PERSIST_WAVES"))) h->persist_waves = atoi(env);
-    if ((env = getenv("ASM_GREEDY_PARK"))) h->g3_park = atoi(env);
-    if ((env = getenv("ASM_GREEDY_PRUNE"))) h->greedy_prune = atoi(env);
-    if ((env = getenv("ASM_PRUNE_WAVES"))) h->prune_waves = atoi(env);
-    if ((env = getenv("ASM_GREEDY_WAVES"))) h->g3_waves = atoi(env);
-    if ((env = getenv("ASM_REFILL_LEAP"))) h->refill_leap = atoi(env);
+    /* The switches the library keeps (read once, here): one fallback per kernel family, the allocator, and the stream layout.
+     * Everything else that used to be switchable was an A/B whose outcome is recorded in DESIGN.md. */
+    const char* env;
+    if ((env = getenv("ASM_OVERLAP"))) h->overlap = env[0] != '0';         /* 0: asm_run_benchmark_async on one stream */
+    if ((env = getenv("ASM_LEAP_HINT"))) h->leap_hint = env[0] != '0';     /* 0: LEAP in input order (no work sort) */
+    if ((env = getenv("ASM_LEAP_SORT"))) h->leap_sort = env[0] != '0';     /* 0: wide-band LEAP sorts inside workgroups only */
+    if ((env = getenv("ASM_BUCKET"))) h->bucketing = env[0] != '0';        /* 0: mixed-length batches in one width class */
+    if ((env = getenv("ASM_WAVE"))) h->wave_kernels = env[0] != '0';       /* 0: workgroup-per-pair fallbacks (asm_wide.h) */
+    if ((env = getenv("ASM_POOL"))) h->pooling = env[0] != '0';            /* 0: plain hipMalloc / hipFree */
+    if ((env = getenv("ASM_NW_BANDED"))) h->nw_banded = env[0] != '0';     /* 0: full-height bit-parallel NW */
+    if ((env = getenv("ASM_NW_BYLEN"))) h->nw_bylen = env[0] != '0';       /* 0: mixed-length NW without the length sort */
+    if ((env = getenv("ASM_NW_WFA"))) h->nw_wfa = env[0] != '0';           /* 0: affine NW by the full matrix only */
+    if ((env = getenv("ASM_GREEDY_FAST"))) h->greedy_fast = env[0] != '0'; /* 0: FP64 Greedy kernel at k <= 3 */
     {
         std::lock_guard<std::mutex> lk(g_live_mu);
+        h->serial = g_next_serial++;
         g_live_handles.push_back(h);
     }
     *out = h;
@@ -759,8 +654,10 @@ int asm_destroy(asm_handle* h) {
     if (h->ev_nw) (void)hipEventDestroy(h->ev_nw);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->ev_switch) (void)hipEventDestroy(h->ev_switch);
     if (h->d_todo) (void)hipFree(h->d_todo);
-    if (h->d_g3_table) (void)hipFree(h->d_g3_table);
+    for (auto& t : h->g3_tables)
+        if (t.d) (void)hipFree(t.d);
     for (hipEvent_t ev : h->prof_ev) (void)hipEventDestroy(ev);
     (void)hipDeviceSynchronize();
     for (char* q : h->pin_raw)
@@ -777,14 +674,14 @@ int asm_destroy(asm_handle* h) {
 const char* asm_last_error(const asm_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
 
 /* The pool recycles freed blocks in the order of the handle's stream.  When that stream changes, work queued on the old one may
- * still use blocks that are already back in the pool: drain the old stream once, so that whatever is handed out under the new
- * stream is really free. */
+ * still use blocks that are live now and go back to the pool later (or are idle already): everything enqueued under the new
+ * stream is therefore ordered behind everything enqueued so far on the old one — an event, no host wait. */
 static int switch_stream(asm_handle* h, hipStream_t next) {
     if (next == h->stream) return ASM_OK;
-    if (h->pooling && !h->pool_idle.empty()) {
-        HIPCHK(h, hipSetDevice(h->device));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-    }
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipEventRecord(h->ev_switch, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(next, h->ev_switch, 0));
+    if (h->tail_set) HIPCHK(h, hipStreamWaitEvent(next, h->ev_tail, 0)); /* overlapped calls end on the library's own streams */
     h->stream = next;
     return ASM_OK;
 }
@@ -905,18 +802,19 @@ static hipError_t launch_pack(asm_handle* h, const asm_batch* b, const uint4* ta
     if (stage < 2048) stage = 2048;
     const size_t lds = stage + 256; /* + the over-read slack of pack_convert and the 64 bytes of padding behind the staged data
                                        (pack_pad; the swizzle stays inside a 128-byte row) */
-#define PACK_LAUNCH(W)                                                                                                    \
-    if (stage <= 7 * PACK_BLOCK * 16)                                                                                      \
-        hipLaunchKernelGGL((pack_kernel<W, 7>), grid, block, lds, h->stream, b->d_reads, b->d_read_off, b->d_refs,        \
-                           b->d_ref_off, tails, planes, lens, (long)b->n, pb, pos, (uint32_t)stage);                      \
-    else                                                                                                                  \
-        hipLaunchKernelGGL((pack_kernel<W, 12>), grid, block, lds, h->stream, b->d_reads, b->d_read_off, b->d_refs,       \
-                           b->d_ref_off, tails, planes, lens, (long)b->n, pb, pos, (uint32_t)stage)
+#define PACK_LAUNCH(W, NV)                                                                                               \
+    hipLaunchKernelGGL((pack_kernel<W, NV>), grid, block, lds, h->stream, b->d_reads, b->d_read_off, b->d_refs,          \
+                       b->d_ref_off, tails, planes, lens, (long)b->n, pb, pos, (uint32_t)stage)
+    /* NV = staging vectors a thread may hold in registers: 7 covers 256 strings of up to 108 characters (28 KB), which only a
+     * one-granule batch can be; everything longer takes 12 */
     switch (wmax) {
-        case 1: PACK_LAUNCH(1); break;
-        case 2: PACK_LAUNCH(2); break;
-        case 3: PACK_LAUNCH(3); break;
-        default: PACK_LAUNCH(4); break;
+        case 1:
+            if (stage <= 7 * PACK_BLOCK * 16) PACK_LAUNCH(1, 7);
+            else PACK_LAUNCH(1, 12);
+            break;
+        case 2: PACK_LAUNCH(2, 12); break;
+        case 3: PACK_LAUNCH(3, 12); break;
+        default: PACK_LAUNCH(4, 12); break;
     }
 #undef PACK_LAUNCH
     return hipGetLastError();
@@ -1082,7 +980,7 @@ int asm_batch_upload(asm_handle* h, int64_t n, const char* reads, const uint32_t
     if (maxlen > ASM_MAX_LENGTH)
         return fail(h, ASM_EUNSUPPORTED, "asm_batch_upload: a sequence is longer than ASM_MAX_LENGTH");
     asm_batch* b = new asm_batch;
-    b->owner = h;
+    b->owner = h, b->owner_serial = h->serial;
     b->n = n;
     b->maxlen = maxlen;
     b->greedy_mode = greedy_mode;
@@ -1124,7 +1022,7 @@ int asm_batch_generate(asm_handle* h, const asm_gen_config* cfg, int64_t first, 
     *out = nullptr;
     HIPCHK(h, hipSetDevice(h->device));
     asm_batch* b = new asm_batch;
-    b->owner = h;
+    b->owner = h, b->owner_serial = h->serial;
     b->n = n;
     b->greedy_mode = greedy_mode;
     uint32_t *d_m = nullptr, *d_n = nullptr, *d_max = nullptr;
@@ -1244,7 +1142,7 @@ int asm_batch_from_hits(asm_handle* h, const asm_reference* ref, int64_t n, cons
     }
     if (maxlen + 1 > ASM_MAX_LENGTH) return fail(h, ASM_EUNSUPPORTED, "asm_batch_from_hits: a read is longer than ASM_MAX_LENGTH - 1");
     asm_batch* b = new asm_batch;
-    b->owner = h;
+    b->owner = h, b->owner_serial = h->serial;
     b->n = n;
     b->maxlen = maxlen + 1; /* the window is one base longer than the read (mapper/main.cpp:80) */
     b->greedy_mode = greedy_mode;
@@ -1335,12 +1233,14 @@ int asm_batch_resolve_tails(asm_handle* h, asm_batch* b, const uint8_t* state) {
 
 int asm_batch_free(asm_handle* h, asm_batch* b) {
     if (!b) return ASM_OK;
-    /* The device blocks belong to the pool of the handle that created the batch (b->owner), whichever handle is named here:
-     * they go back THERE.  If that handle is gone, asm_destroy has released every block of its pool, this batch's included, and
-     * only the record is left (h may then be NULL). */
+    /* The device blocks belong to the pool of the handle that created the batch, whichever handle is named here (h may be NULL):
+     * they go back THERE.  The owner is named by (address, serial): if that handle is gone — asm_destroy has released every
+     * block of its pool, this batch's included — only the record is left, also when a NEW handle lives at the old address.
+     * Look-up and release happen under one lock, so the owner cannot be destroyed in between. */
     (void)h;
-    if (!handle_is_live(b->owner)) {
-        for (hipEvent_t ev : b->ev_consumed)
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    if (!owner_is_live_locked(b->owner, b->owner_serial)) {
+        for (hipEvent_t ev : b->ev_consumed) /* events belong to the device context, not to the handle */
             if (ev) (void)hipEventDestroy(ev);
         delete b;
         return ASM_OK;
@@ -1352,6 +1252,7 @@ int asm_batch_free(asm_handle* h, asm_batch* b) {
 
 int64_t asm_batch_size(const asm_batch* b) { return b ? b->n : 0; }
 int asm_batch_max_length(const asm_batch* b) { return b ? b->maxlen : 0; }
+int64_t asm_batch_text_bytes(const asm_batch* b) { return b ? (int64_t)(b->reads_bytes + b->refs_bytes) : 0; }
 
 int asm_batch_download(asm_handle* h, const asm_batch* b, uint32_t* read_off, uint32_t* ref_off, char* reads,
                        size_t reads_cap, char* refs, size_t refs_cap) {
@@ -1426,21 +1327,16 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
             case 4: HIPCHK(h, launch_greedy<4>(h, b, ga, out, cig)); break;
             case 5: HIPCHK(h, launch_greedy<5>(h, b, ga, out, cig)); break;
 #define GREEDY_WIDE_CASE(KK) \
-            case KK: if (h->persist_wide && h->persist && p->k == KK) { HIPCHK(h, launch_greedy<KK>(h, b, ga, out, cig)); break; } /* else: falls through to the kernels below */
+            case KK: if (unit && !ga.semi) { HIPCHK(h, launch_greedy<KK>(h, b, ga, out, cig)); break; } /* general penalties: the kernels below */
             GREEDY_WIDE_CASE(6) GREEDY_WIDE_CASE(7) GREEDY_WIDE_CASE(8) GREEDY_WIDE_CASE(9) GREEDY_WIDE_CASE(10) GREEDY_WIDE_CASE(11)
             GREEDY_WIDE_CASE(12) GREEDY_WIDE_CASE(13) GREEDY_WIDE_CASE(14) GREEDY_WIDE_CASE(15) GREEDY_WIDE_CASE(16)
             /* K = 17, 18 still win at 100 bp (0.71, 0.79 ms against 0.90) but lose at 150 bp, err 0.20 (1.67, 1.83 against 1.60) */
 #undef GREEDY_WIDE_CASE
             default:
-                if (h->group_kernels && p->k >= 32 && p->k <= 39 && (long)p->o + 110L * p->e < 16000L) {
+                if (h->wave_kernels && p->k >= 32 && p->k <= 39 && (long)p->o + 110L * p->e < 16000L) {
                     /* 65..79 band lanes: sixteen threads per pair, five lanes each (asm_group.h): 1.78 ms per 10^6 C2 pairs
                      * against 2.25 ms for the two-wavefront kernel */
                     HIPCHK(h, launch_greedy_group(h->stream, planes, lens, b.n, b.w4, (int)p->k, ga, out, cig, h->num_cus));
-                } else if (p->k <= PR_MAXK && h->greedy_prune > 0 && p->k >= h->greedy_prune && h->wave_kernels && unit && !ga.semi &&
-                           ga.sig_mismatch <= 0.0 && ga.sig_indel <= 0.0 && ga.sig_match >= 0.0) {
-                    /* a pass looks at the few lanes that can matter (exact pruning, asm_greedy_prune.h) */
-                    const int prc = launch_greedy_pruned(h, b, (int)p->k, ga, out, cig);
-                    if (prc != ASM_OK) return prc;
                 } else if (p->k <= ASM_WAVE_MAX_K && h->wave_kernels && unit && !ga.semi) {
                     HIPCHK(h, hipMemsetAsync(h->d_pair_queue, 0, sizeof(unsigned long long), h->stream));
                     launch_wave_per_pair(h->stream, greedy_wave_kernel<true>, b.n, h->num_cus, planes, lens, (long)b.n, b.w4,
@@ -1478,7 +1374,7 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
                 case 4: HIPCHK(h, launch_leap_general<4>(h, b, p, out)); break;
                 default: HIPCHK(h, launch_leap_general<5>(h, b, p, out)); break;
             }
-        } else if (h->wave_kernels && ((unit && (h->leap_quad & 1)) || (!unit && (h->leap_quad & 2))) && b.maxlen <= 512 &&
+        } else if (h->wave_kernels && b.maxlen <= 512 &&
                    leap_quad_lds((b.maxlen + 31) / 32, (int)p->k, unit ? 2 : RingGeometry(p->x, p->o, p->e).gm,
                                  unit ? 0 : RingGeometry(p->x, p->o, p->e).gi, b.maxlen + 2 <= 255 ? 1 : 2) <= 64 * 1024) {
             /* wide band: four threads per pair, generation rings and planes in LDS (asm_wave.h) */
@@ -1523,48 +1419,6 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
             else if (w32 <= 12) LEAP_QUAD(12);
             else LEAP_QUAD(16);
 #undef LEAP_QUAD
-        } else if (unit && h->leap_band && h->wave_kernels &&
-                   leap_band_lds((b.maxlen + 31) / 32, (int)p->k, b.maxlen + 2 <= 255 ? 1 : 2) <= 64 * 1024) {
-            /* wide band, unit penalties: thread per pair, band and planes in LDS (asm_wave.h) */
-            const int w32 = (b.maxlen + 31) / 32;
-#define LEAP_BAND(W)                                                                                                        \
-    HIPCHK(h, (b.maxlen + 2 <= 255 ? launch_leap_band<W, uint8_t>(h->stream, planes, lens, b.n, b.w4, (int)p->k, out)       \
-                                   : launch_leap_band<W, uint16_t>(h->stream, planes, lens, b.n, b.w4, (int)p->k, out)))
-            if (w32 <= 4) LEAP_BAND(4);
-            else if (w32 <= 5) LEAP_BAND(5);
-            else if (w32 <= 6) LEAP_BAND(6);
-            else if (w32 <= 8) LEAP_BAND(8);
-            else if (w32 <= 12) LEAP_BAND(12);
-            else LEAP_BAND(16);
-#undef LEAP_BAND
-        } else if (!unit && h->leap_band && h->wave_kernels &&
-                   leap_band_general_lds((b.maxlen + 31) / 32, (int)p->k, RingGeometry(p->x, p->o, p->e).gm,
-                                         RingGeometry(p->x, p->o, p->e).gi, b.maxlen + 2 <= 255 ? 1 : 2) <= 80 * 1024) { /* two workgroups per CU at least */
-            /* wide band, general penalties: thread per pair, generation rings and planes in LDS (asm_wave.h) */
-            const RingGeometry rg(p->x, p->o, p->e);
-            const int w32 = (b.maxlen + 31) / 32;
-#define LEAP_BANDG(W)                                                                                                          \
-    HIPCHK(h, (b.maxlen + 2 <= 255                                                                                              \
-                   ? launch_leap_band_general<W, uint8_t>(h->stream, planes, lens, b.n, b.w4, (int)p->k, (int)p->x, (int)p->o,   \
-                                                          (int)p->e, rg.gm, rg.gi, out)                                          \
-                   : launch_leap_band_general<W, uint16_t>(h->stream, planes, lens, b.n, b.w4, (int)p->k, (int)p->x, (int)p->o,  \
-                                                           (int)p->e, rg.gm, rg.gi, out)))
-            if (w32 <= 4) LEAP_BANDG(4);
-            else if (w32 <= 5) LEAP_BANDG(5);
-            else if (w32 <= 6) LEAP_BANDG(6);
-            else if (w32 <= 8) LEAP_BANDG(8);
-            else if (w32 <= 12) LEAP_BANDG(12);
-            else LEAP_BANDG(16);
-#undef LEAP_BANDG
-        } else if (unit && p->k <= ASM_WAVE_MAX_K && h->wave_kernels) {
-#define LEAP_WAVE(W) \
-    launch_wave_per_pair(h->stream, leap_wave_kernel<W>, b.n, h->num_cus, planes, lens, (long)b.n, b.w4, (int)p->k, out)
-            if (b.maxlen <= 128) LEAP_WAVE(2);
-            else if (b.maxlen <= 192) LEAP_WAVE(3);
-            else if (b.maxlen <= 256) LEAP_WAVE(4);
-            else if (b.maxlen <= 384) LEAP_WAVE(6);
-            else LEAP_WAVE(8);
-#undef LEAP_WAVE
         } else {
             launch_leap_wide(h->stream, planes, lens, b.n, b.w4, p->k, p->x, p->o, p->e, out);
         }
@@ -1843,7 +1697,7 @@ static int simd_ed_affine_launch(asm_handle* h, const asm_batch* b, int gap_thre
         out.out = d_ed;
         out.order = k.order;
         const dim3 grid((unsigned)((k.n + threads - 1) / threads)), block((unsigned)threads);
-        if (k.maxlen <= 128 && gap_threshold >= h->simd_quad_min) { /* four threads per pair */
+        if (k.maxlen <= 128) { /* four threads per pair (thread per pair measured 0.28/0.71/3.5 ms per 10^6 C2 pairs at gap 3/8/30 against 0.29/0.46/0.79) */
             const size_t qlds = simd_quad_lds(gap_threshold, rg.gm, rg.gi);
             hipLaunchKernelGGL(simd_ed_affine_quad_kernel, dim3((unsigned)((k.n + 15) / 16)), dim3(64), qlds, h->stream, k.planes, k.lens,
                                (long)k.n, k.w4, gap_threshold, af_threshold, x, o, e, rg.gm, rg.gi, mode, out);
@@ -1930,7 +1784,7 @@ int asm_count_equal_async(asm_handle* h, const int32_t* d_a, const int32_t* d_b,
 
 int asm_accuracy_async(asm_handle* h, const int32_t* d_nw, const int32_t* d_leap, const int32_t* d_greedy,
                        const int32_t* d_answers, int64_t n, unsigned long long* d_counters) {
-    if (!h || !d_nw || !d_counters) return fail(h, ASM_EINVAL, "asm_accuracy_async: NULL argument");
+    if (!h || !d_counters) return fail(h, ASM_EINVAL, "asm_accuracy_async: NULL argument");
     if (n <= 0) return ASM_OK;
     if ((((uintptr_t)d_nw | (uintptr_t)d_leap | (uintptr_t)d_greedy | (uintptr_t)d_answers) & 15u) != 0)
         return fail(h, ASM_EINVAL, "asm_accuracy_async: penalty arrays must be 16-byte aligned");
@@ -1939,6 +1793,7 @@ int asm_accuracy_async(asm_handle* h, const int32_t* d_nw, const int32_t* d_leap
     /* every workgroup ends with three atomics on one cache line, and a hot line takes only ~90 atomics/us: 977 workgroups
      * made this kernel 38 us at 10^6 pairs (rocprof, round 1); 128 grid-striding workgroups keep the loads wide enough */
     blocks = blocks < 1 ? 1 : (blocks > 128 ? 128 : blocks);
+    if (!d_nw && !d_answers) blocks = 1; /* nothing to compare with: total_tests only */
     hipLaunchKernelGGL(accuracy_kernel, dim3((unsigned)blocks), dim3(ASM_BLOCK), 0, h->stream, d_nw, d_leap, d_greedy,
                        d_answers, (long)n, d_counters);
     HIPCHK(h, hipGetLastError());
@@ -1986,6 +1841,13 @@ int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, in
                             unsigned long long* d_counters) {
     if (!h || !b || !p) return fail(h, ASM_EINVAL, "asm_run_benchmark_async: NULL argument");
     int rc = ASM_OK;
+    // Without NW in the mask, wide-band LEAP (four threads per pair, asm_wave.h) is scheduled by the Greedy penalties:
+    // Greedy first, on the same stream — at wide bands both kernels are VALU-bound and side by side they gain nothing (C3:
+    // 23.8 ms against 23.6 in a row), while the work-sorted LEAP saves a quarter of its time.
+    const bool greedy_first_shape = d_greedy && d_leap && !d_nw && p->k > 5 && h->leap_hint && h->wave_kernels;
+    /* A call that asks for overlapped steps but has the Greedy-first shape (or no pairs) runs as a pipelined-pack call: it is
+     * ordered like one (behind every earlier overlapped call), and the bookkeeping of the overlapped form starts afresh. */
+    if (repack == 3 && (b->n <= 0 || greedy_first_shape)) repack = 2;
     // optional per-kernel timing inside the caller's timed region: events on the stream each kernel is launched on
     hipEvent_t* pe = nullptr;
     unsigned pmask = 0u;
@@ -2002,7 +1864,7 @@ int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, in
                                           (d_greedy && d_greedy == h->last3_out[2])))
         return fail(h, ASM_EINVAL, "asm_run_benchmark_async: repack = 3 needs output arrays that alternate between two sets (these "
                                    "were the previous call's); asm_pipeline_join_async first to reuse them");
-    if (repack != 3) h->last3_valid = false;
+    if (repack != 3) h->last3_valid = false, h->calls3 = 0;
     if (repack != 3 && h->tail_set) { /* earlier overlapped calls: everything of theirs before anything of this one */
         HIPCHK(h, hipSetDevice(h->device));
         HIPCHK(h, hipStreamWaitEvent(main_stream, h->ev_tail, 0));
@@ -2039,8 +1901,7 @@ int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, in
          * workgroups, dispatched at the same moment, keep Greedy's 122 KB-LDS workgroups off the CUs (0.280 ms/step); behind
          * the previous NW they find Greedy running and take the slots NW left (0.238).  With overlapped calls (repack = 3) the
          * pack chain runs a call ahead and meets no Greedy launch: no gate there (0.229 against 0.251 gated) */
-        const int gate = h->pack_gate >= 0 ? h->pack_gate : (repack == 2 ? 1 : 0);
-        if (h->gate_set && gate) HIPCHK(h, hipStreamWaitEvent(h->pack_stream, h->ev_gate, 0));
+        if (h->gate_set && repack == 2) HIPCHK(h, hipStreamWaitEvent(h->pack_stream, h->ev_gate, 0));
         PROF(0, 0, h->pack_stream)
         h->stream = h->pack_stream;
         rc = asm_batch_pack_async(h, b);
@@ -2058,16 +1919,13 @@ int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, in
     }
     // Greedy depends only on the packed planes, NW -> LEAP form their own chain (LEAP is scheduled by the NW penalties):
     // run Greedy on a side stream so that the two chains fill each other's launch gaps and tail waves.
-    // Without NW in the mask, wide-band LEAP (four threads per pair, asm_wave.h) is scheduled by the Greedy penalties instead:
-    // Greedy first, on the same stream — at wide bands both kernels are VALU-bound and side by side they gain nothing (C3:
-    // 23.8 ms against 23.6 in a row), while the work-sorted LEAP saves a quarter of its time.
-    const bool greedy_first = d_greedy && d_leap && !d_nw && p->k > 5 && h->leap_quad != 0 && h->leap_hint && h->wave_kernels && !rc;
+    const bool greedy_first = greedy_first_shape && !rc;
     if (greedy_first) {
         PROF(3, 0, main_stream)
         rc = asm_align_batch_async(h, b, ASM_GREEDY, p, d_greedy);
         PROF(3, 1, main_stream)
     }
-    if (repack == 3 && pipelined && !greedy_first && !rc) {
+    if (repack == 3 && pipelined && !rc) {
         h->last3_out[0] = d_nw, h->last3_out[1] = d_leap, h->last3_out[2] = d_greedy;
         h->last3_valid = true;
         /* OVERLAPPED calls: nothing of this call waits for the previous call's Greedy, and the caller's stream is not joined
@@ -2099,16 +1957,12 @@ int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, in
             PROF(1, 0, main_stream)
             rc = asm_align_batch_async(h, b, ASM_NW, p, d_nw);
             PROF(1, 1, main_stream)
-            if (!rc && h->pack_gate == 1) {
-                HIPCHK(h, hipEventRecord(h->ev_gate, main_stream));
-                h->gate_set = true;
-            }
         }
         /* LEAP on the counters' stream when there is an NW to wait for: the next call's NW then follows this call's NW directly,
          * and the chain on that stream is LEAP -> counters -> LEAP.  (The HIP runtime spreads streams over four hardware queues:
          * a fifth busy stream shares a queue with another and serialises with it — measured 0.26-0.29 ms per step —, so LEAP
          * gets no stream of its own.) */
-        hipStream_t ls = (h->leap_own && d_nw && d_leap) ? h->acc_stream : main_stream;
+        hipStream_t ls = (d_nw && d_leap) ? h->acc_stream : main_stream;
         if (!rc && d_leap) {
             if (ls != main_stream) {
                 HIPCHK(h, hipEventRecord(h->ev_nw, main_stream));
@@ -2119,17 +1973,13 @@ int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, in
             rc = asm_align_batch_hinted_async(h, b, ASM_LEAP, p, d_nw, d_leap);
             h->stream = main_stream;
             PROF(2, 1, ls)
-            if (!rc && h->pack_gate == 2) { /* (explicit ASM_PACK_GATE only) */
-                HIPCHK(h, hipEventRecord(h->ev_gate, ls));
-                h->gate_set = true;
-            }
         }
         if (pe) h->prof_mask.push_back(pmask);
         if (rc) return rc;
         HIPCHK(h, hipEventRecord(h->ev_leap, ls));
         HIPCHK(h, hipStreamWaitEvent(h->acc_stream, h->ev_leap, 0));
         if (d_greedy) HIPCHK(h, hipStreamWaitEvent(h->acc_stream, h->ev_join, 0));
-        if (d_counters && d_nw) {
+        if (d_counters) {
             h->stream = h->acc_stream;
             rc = asm_accuracy_async(h, d_nw, d_leap, d_greedy, d_answers, b->n, d_counters);
             h->stream = main_stream;
@@ -2158,7 +2008,7 @@ int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, in
         PROF(1, 0, main_stream)
         rc = asm_align_batch_async(h, b, ASM_NW, p, d_nw);
         PROF(1, 1, main_stream)
-        if (!rc && (h->pack_gate == 1 || (h->pack_gate < 0 && repack == 2))) {
+        if (!rc && repack == 2) {
             HIPCHK(h, hipEventRecord(h->ev_gate, main_stream));
             h->gate_set = true;
         }
@@ -2168,10 +2018,6 @@ int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, in
         PROF(2, 0, main_stream)
         rc = asm_align_batch_hinted_async(h, b, ASM_LEAP, p, greedy_first ? d_greedy : d_nw, d_leap);
         PROF(2, 1, main_stream)
-        if (!rc && h->pack_gate == 2) {
-            HIPCHK(h, hipEventRecord(h->ev_gate, main_stream));
-            h->gate_set = true;
-        }
     }
     if (fork) {
         if (!rc) HIPCHK(h, hipStreamWaitEvent(main_stream, h->ev_join, 0));
@@ -2183,7 +2029,7 @@ int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, in
 #undef PROF
     if (pe) h->prof_mask.push_back(pmask);
     if (pipelined && !rc) HIPCHK(h, hipEventRecord(b->ev_consumed[b->cur], main_stream)); /* Greedy's stream has joined above */
-    if (!rc && d_counters && d_nw) rc = asm_accuracy_async(h, d_nw, d_leap, d_greedy, d_answers, b->n, d_counters);
+    if (!rc && d_counters) rc = asm_accuracy_async(h, d_nw, d_leap, d_greedy, d_answers, b->n, d_counters);
     h->pipe_prev = pipelined;
     return rc;
 }
@@ -2357,7 +2203,7 @@ static NlScan read_and_scan(StreamWorkers& pool, int fd, char* buf, size_t head,
 static int batch_from_device_text(asm_handle* h, const char* d_raw, size_t nbytes, int64_t n, int greedy_mode, asm_batch** out) {
     *out = nullptr;
     asm_batch* b = new asm_batch;
-    b->owner = h;
+    b->owner = h, b->owner_serial = h->serial;
     b->n = n;
     b->greedy_mode = greedy_mode;
     uint32_t *d_tile = nullptr, *d_tbase = nullptr, *d_nl = nullptr, *d_m = nullptr, *d_n = nullptr, *d_max = nullptr;
@@ -2703,15 +2549,7 @@ int asm_stream_seq_file(asm_handle* h, const char* path, const asm_params* p, in
         if (rc) return;
         STREAM_TRY(hipStreamWaitEvent(h->stream, ev_h2d[q], 0));
         asm_batch* b = nullptr;
-        const auto tp0 = std::chrono::steady_clock::now();
-        static const bool stream_debug = getenv("ASM_STREAM_DEBUG") != nullptr; /* development: per-chunk timings on stderr */
-        if (stream_debug) (void)hipEventSynchronize(ev_h2d[q]);
-        const auto tp1 = std::chrono::steady_clock::now();
         if (!rc) rc = batch_from_device_text(h, d_raw[q], shipped, n, ASM_GREEDY_CLEAN, &b);
-        const auto tp2 = std::chrono::steady_clock::now();
-        if (stream_debug)
-            fprintf(stderr, "chunk %ld pairs: wait h2d %.3f ms, parse+pack %.3f ms\n", (long)n,
-                    std::chrono::duration<double, std::milli>(tp1 - tp0).count(), std::chrono::duration<double, std::milli>(tp2 - tp1).count());
         if (rc) return;
         if (greedy_mode == ASM_GREEDY_SEQUENTIAL && do_greedy) { /* the chain of hurdle_matrix.h:136-137 across chunk boundaries */
             uint8_t summary[256];
@@ -2734,7 +2572,7 @@ int asm_stream_seq_file(asm_handle* h, const char* path, const asm_params* p, in
         }
         if (!rc)
             rc = asm_run_benchmark_async(h, b, p, 0, do_nw ? d_pen[q][0] : nullptr, do_leap ? d_pen[q][1] : nullptr,
-                                         do_greedy ? d_pen[q][2] : nullptr, ans, do_nw ? d_cnt : nullptr);
+                                         do_greedy ? d_pen[q][2] : nullptr, ans, d_cnt);
         for (int a = 0; a < 3 && !rc; a++)
             if (d_pen[q][a]) STREAM_TRY(hipMemcpyAsync(h_pen[q][a], d_pen[q][a], sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
         STREAM_TRY(hipEventRecord(ev_done[q], h->stream));
@@ -2784,7 +2622,6 @@ int asm_stream_seq_file(asm_handle* h, const char* path, const asm_params* p, in
     stats->pairs = done_pairs, stats->chunks = chunks, stats->bytes = (int64_t)bytes_total, stats->max_length = maxlen;
     stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     stats->seconds_read = read_seconds;
-    if (!do_nw) stats->counters[0] = (unsigned long long)done_pairs;
     return rc;
 }
 

@@ -31,7 +31,7 @@ __device__ __forceinline__ G3V g3_from_uint4(uint4 q) {
 template <int K, int NT>
 __global__ __launch_bounds__(NT) void greedy_fast_kernel(const uint4* __restrict__ planes, const uint32_t* __restrict__ lens,
                                                          long n, int w4, G3Sig sig, const uint2* __restrict__ table_g,
-                                                         OutMap out, CigarSink cig, int refill_min, int park) {
+                                                         OutMap out, CigarSink cig, int refill_min) {
     constexpr int NL = 2 * K + 1;
     extern __shared__ uint4 g3_smem[];
     uint2* const tab = reinterpret_cast<uint2*>(g3_smem);
@@ -68,18 +68,9 @@ __global__ __launch_bounds__(NT) void greedy_fast_kernel(const uint4* __restrict
 #ifdef GREEDY_DIAG
     unsigned long long dg_refill = 0, dg_step = 0, dg_iters = 0, dg_lanes = 0, dg_t0 = __builtin_amdgcn_s_memtime();
 #endif
-    // DRAIN COMPACTION (park != 0).  When the workgroup's counter has run dry a wave is left with its last pairs, fewer in every
-    // iteration (a pair of seven passes takes seven iterations whoever else is done), and an iteration costs a wave the same
-    // issue slots with 3 live lanes as with 64.  So a wave that is down to 64 / (waves per workgroup) live pairs PARKS them —
-    // sixteen dwords of state per pair in LDS; the lane vectors stay where they are, in the wave's LDS columns — and ends; the
-    // wave that parks last takes all parked pairs of the workgroup (at most 64) into its lanes and runs one shared tail.  No
-    // wave ever waits for another: who is last is decided by the counter every wave bumps after its entries are written.
-    constexpr int NWAVES = NT / 64, PARK_T = 64 / NWAVES;
-    __shared__ unsigned int g3_parked, g3_done;
-    __shared__ uint32_t g3_park[64 * 16];
-    if (threadIdx.x == 0) g3_parked = 0u, g3_done = 0u;
-    __syncthreads();
-    bool adopter = false;
+    // (Measured and removed in round 4: DRAIN COMPACTION — a wave down to 64 / (waves per workgroup) live pairs parked them in LDS
+    // and ended, the wave that parked last adopted all of them.  Fewer wave-iterations, bit-identical, and slower in every form
+    // of the step: 125 us against 112 stand-alone, 0.234 against 0.230 ms per overlapped step.  Last present in commit 312851a.)
     for (;;) {
 #ifdef GREEDY_DIAG
         const unsigned long long dg_a = __builtin_amdgcn_s_memtime();
@@ -146,72 +137,6 @@ __global__ __launch_bounds__(NT) void greedy_fast_kernel(const uint4* __restrict
         dg_iters++;
         dg_lanes += __popcll(__ballot(active && !s.finished));
 #endif
-        if (park != 0 && !adopter) {
-            const bool live = active && !s.finished;
-            const unsigned long long live_mask = __ballot(live);
-            const bool flushed = __ballot(s.finished && !exhausted) == 0ull; /* every finished pair has been written out */
-            if (__ballot(exhausted) != 0ull && flushed && __popcll(live_mask) <= PARK_T) {
-                unsigned int base = 0u;
-                if ((threadIdx.x & 63) == 0 && live_mask != 0ull) base = atomicAdd(&g3_parked, (unsigned int)__popcll(live_mask));
-                base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
-                if (live) {
-                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(live_mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)live_mask, 0u));
-                    uint32_t* e = g3_park + 16 * (base + (unsigned int)rank);
-#pragma unroll
-                    for (int j = 0; j < NL; j++) /* sp, en in -1 .. 128; nsw 0 .. 2K; dst may be below 0 for strings shorter than the band */
-                        e[j] = (uint32_t)(s.sp[j] + 1) | ((uint32_t)(s.en[j] + 1) << 8) | ((uint32_t)s.nsw[j] << 16) | ((uint32_t)(s.dst[j] + 16) << 24);
-                    e[NL + 0] = (uint32_t)s.m | ((uint32_t)s.n << 8) | ((uint32_t)s.cur_col << 16) | ((uint32_t)(s.cur_lane + 16) << 24);
-                    e[NL + 1] = (uint32_t)(s.dest_lane + 256) | ((uint32_t)threadIdx.x << 16);
-                    e[NL + 2] = (uint32_t)s.cost;
-                    e[NL + 3] = (uint32_t)s.guard;
-                    e[NL + 4] = (uint32_t)idx;
-                    e[NL + 5] = (uint32_t)ncig;
-                }
-                __threadfence_block();
-                unsigned int order = 0u;
-                if ((threadIdx.x & 63) == 0) order = atomicAdd(&g3_done, 1u);
-                order = (unsigned int)__builtin_amdgcn_readfirstlane((int)order);
-                if (order != (unsigned int)(NWAVES - 1)) return; /* not the last to park: this wave is done */
-                __threadfence_block();
-                const unsigned int total = *(volatile unsigned int*)&g3_parked; /* <= NWAVES * PARK_T <= 64 */
-                adopter = true;
-                const int t = (int)(threadIdx.x & 63);
-                active = (unsigned int)t < total;
-                exhausted = !active; /* an adopted pair still goes through the refill block when it is done: final hop and output */
-                s.finished = !active;
-                if (active) {
-                    const uint32_t* e = g3_park + 16 * t;
-#pragma unroll
-                    for (int j = 0; j < NL; j++) {
-                        const uint32_t w = e[j];
-                        s.sp[j] = (int)(w & 255u) - 1, s.en[j] = (int)((w >> 8) & 255u) - 1, s.nsw[j] = (int)((w >> 16) & 255u);
-                        s.dst[j] = (int)(w >> 24) - 16;
-                    }
-                    const uint32_t w0 = e[NL + 0], w1 = e[NL + 1];
-                    s.m = (int)(w0 & 255u), s.n = (int)((w0 >> 8) & 255u), s.cur_col = (int)((w0 >> 16) & 255u);
-                    s.cur_lane = (int)(w0 >> 24) - 16;
-                    s.dest_lane = (int)(w1 & 0xffffu) - 256;
-                    const G3V* src = vecs + (w1 >> 16); /* the parking thread's column of lane vectors */
-                    s.cost = (int)e[NL + 2], s.guard = (int)e[NL + 3];
-                    idx = (long)e[NL + 4];
-                    ncig = (int)e[NL + 5];
-                    pair = out.index(idx);
-#pragma unroll
-                    for (int j = 0; j < NL; j++) s.lo[j] = src[j * NT];
-                }
-                /* every lane has read its source column (one wave, program order) before any lane overwrites a column */
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (active) {
-#pragma unroll
-                    for (int j = 0; j < NL; j++) {
-                        store.put(j, s.lo[j]);
-                        s.lf[j] = g3_flip1(s.lo[j]);
-                    }
-                }
-            }
-        }
         if (__ballot(active && !s.finished) == 0ull) break; /* wave-uniform: the slice is used up and every pair is done */
         if (active && !s.finished) {
             const G3Step st = g3_pass<K>(s, table, sig, store);

@@ -355,150 +355,6 @@ ASM_DEV V128 greedy_lane_vector(V128 A0, V128 A1, V128 B0, V128 B1, int lane) {
     return v_or(m0, m1);
 }
 
-template <int K>
-__global__ __launch_bounds__(ASM_BLOCK) void greedy_kernel(const uint4* __restrict__ planes,
-                                                           const uint32_t* __restrict__ lens, long n, int w4,
-                                                           GreedyArgs args, OutMap out, CigarSink cig) {
-    constexpr int NL = 2 * K + 1;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const long pair = out.index(i);
-    int ncig = 0;
-    const V128 A0 = v_from_uint4(planes[((long)0 * w4) * n + i]);
-    const V128 A1 = v_from_uint4(planes[((long)1 * w4) * n + i]);
-    const V128 B0 = v_from_uint4(planes[((long)2 * w4) * n + i]);
-    const V128 B1 = v_from_uint4(planes[((long)3 * w4) * n + i]);
-    const uint32_t ln = lens[i];
-    int m = (int)(ln & 0xffffu), nn = (int)(ln >> 16);
-    m = m > 128 ? 128 : m; /* hurdle_matrix.h:626-627 */
-    nn = nn > 128 ? 128 : nn;
-    const int x = args.x, o = args.o, e = args.e;
-    const bool semi = args.semi != 0;
-    const int dest_lane = nn - m; /* hurdle_matrix.h:649 */
-
-    V128 lo_[NL], lf_[NL];
-    int sp[NL], len[NL], nsw[NL], dst[NL], sw[NL], nh[NL];
-#pragma unroll
-    for (int j = 0; j < NL; j++) {
-        const int lane = j - K;
-        lo_[j] = greedy_lane_vector(A0, A1, B0, B1, lane);
-        lf_[j] = v_flip_short_hurdles1(lo_[j]);
-        sp[j] = -1; /* hurdle_matrix.h:106-119 */
-        len[j] = 0;
-        nsw[j] = 128;
-        dst[j] = lane_destination(m, nn, lane);
-        sw[j] = nh[j] = 128;
-    }
-
-    int cur_lane = 0, cur_col = 0, cost = 0;
-    for (int guard = 0; guard < 4 * 128; guard++) {
-        // ---- _update_highway_list ----
-        bool reaching = false;
-#pragma unroll
-        for (int j = 0; j < NL; j++) {
-            const int lane = j - K;
-            const int start_col = cur_col + fwd_col(cur_lane, lane);
-            if (sp[j] < start_col) {
-                int d = lane - cur_lane;
-                nsw[j] = d < 0 ? -d : d;
-                int fz, nx;
-                v_highway_from(lf_[j], start_col, fz, nx);
-                sp[j] = start_col + fz;
-                len[j] = nx;
-                if (start_col + fz + nx > dst[j]) {
-                    const int c = dst[j] - (start_col + fz);
-                    len[j] = c > 0 ? c : 0;
-                    reaching = true;
-                }
-            }
-            sw[j] = (semi && guard == 0) ? 0 : lane_penalty(cur_lane, lane, o, e);
-            nh[j] = v_pop_between(lo_[j], start_col, sp[j] + len[j]);
-        }
-        double best_h = -__builtin_inf();
-        int best_leap = 0; /* -numeric_limits<int>::infinity() == 0 (hurdle_matrix.h:287) */
-        int best = 0, best_sp = 0, best_len = 0, best_cost = 0;
-        V128 best_vec = v_make(0, 0);
-        bool have = false;
-#pragma unroll
-        for (int j = 0; j < NL; j++) {
-            const int lane = j - K;
-            const int hc = x * nh[j];
-            const int cur_cost = -sw[j] - hc;
-            // no FMA contraction: identical bits on every compiler/target (oracle is built -ffp-contract=off)
-            double heur = greedy_significance(args, len[j], nh[j], nsw[j]);
-            int leap = -sw[j];
-            if (reaching) {
-                const int fsw = semi ? 0 : lane_penalty(lane, dest_lane, o, e);
-                heur = (double)(cur_cost - fsw - x * (dst[j] - sp[j] - len[j]));
-                leap -= fsw;
-            }
-            const bool take = heur > best_h || (heur == best_h && leap > best_leap);
-            if (take) {
-                best_h = heur;
-                best_leap = leap;
-                best = lane;
-                best_sp = sp[j];
-                best_len = len[j];
-                best_cost = hc + sw[j];
-                best_vec = lo_[j];
-                have = true;
-            }
-        }
-        // When no lane ever wins (cannot happen: the first lane beats -inf) the reference's best lane is
-        // lane 0; keep that behaviour for completeness.
-        if (!have) {
-            best = 0;
-            best_sp = sp[K];
-            best_len = len[K];
-            best_cost = x * nh[K] + sw[K];
-            best_vec = lo_[K];
-        }
-        if (best_len <= 0) break; /* hurdle_matrix.h:358-361 */
-
-        // ---- _choose_best_highway ----
-        const int best_from_sp = v_ones_from(best_vec, best_sp);
-        int small_inter = best_cost, small_total = best_cost;
-        int ch = best, ch_sp = best_sp, ch_len = best_len, ch_cost = best_cost;
-#pragma unroll
-        for (int j = 0; j < NL; j++) {
-            const int lane = j - K;
-            if (lane != best && !(sp[j] + fwd_col(lane, best) > best_sp)) {
-                const int endp = sp[j] + len[j];
-                const int inter = sw[j] + nh[j]; /* the same range loop 1 counted: [cur_col + fwd, sp + len) */
-                const int tail = x * v_pop_between_pre(best_vec, fwd_col(lane, best) + endp, best_sp, best_from_sp);
-                const int total = inter + lane_penalty(lane, best, o, e) + (tail > 0 ? tail : 0);
-                if (total <= small_total && inter <= small_inter) {
-                    small_total = total;
-                    small_inter = inter;
-                    ch = lane;
-                    ch_sp = sp[j];
-                    ch_len = len[j];
-                    ch_cost = sw[j] + x * nh[j];
-                }
-            }
-        }
-        // ---- _step commit (hurdle_matrix.h:411-433) ----
-        cost += ch_cost;
-        if (cig.on()) cig.step(pair, ncig, cur_lane, ch, ch_sp + ch_len - (cur_col + fwd_col(cur_lane, ch)));
-        cur_lane = ch;
-        cur_col = ch_sp + ch_len;
-        if (cur_col >= lane_destination(m, nn, ch)) break;
-    }
-    // ---- final hop (hurdle_matrix.h:575-590); the destination lane vector is built directly (it may lie
-    // outside the band: own behaviour for the reference's undefined case) ----
-    const int dest_col = lane_destination(m, nn, dest_lane);
-    if (cur_lane != dest_lane || cur_col < dest_col) {
-        const V128 dv = greedy_lane_vector(A0, A1, B0, B1, dest_lane);
-        const int sw_f = semi ? 0 : lane_penalty(cur_lane, dest_lane, o, e);
-        const int distance = v_pop_between(dv, cur_col + fwd_col(cur_lane, dest_lane), dest_col);
-        const int hc = x * distance;
-        cost += sw_f + (hc > 0 ? hc : 0);
-        if (cig.on()) cig.step(pair, ncig, cur_lane, dest_lane, distance); /* the hurdle count, not the distance (:589) */
-    }
-    if (cig.on()) cig.finish(pair, ncig);
-    out.put(i, cost);
-}
-
 // Wave-local work queue for the persistent kernels: every wave owns a contiguous slice [q_next, q_end) of the batch
 // (static split over the resident waves: ~n/3000 pairs each, so slices are balanced to a few percent) and its lanes pull
 // the next pair with wave-level bit tricks only — no memory atomics (a single global queue head saturates at ~88
@@ -529,7 +385,7 @@ struct WaveQueue {
 };
 
 // --------------------------------------------------------------------------------------------------------
-// Persistent, lane-refilling form of greedy_kernel<K>.  Pairs need 1..7 steps each (mean ~2 at err 0.10); with one
+// Persistent, lane-refilling thread-per-pair Greedy kernel.  Pairs need 1..7 steps each (mean ~2 at err 0.10); with one
 // pair per thread a wave runs as long as its slowest pair and the other lanes idle.  Here a wave keeps all 64
 // lanes busy: whenever a lane's pair terminates it writes the result and pulls the next pair index from a global
 // wave-local queue (WaveQueue above), so every pass of the step body works on 64 live pairs.  The grid is sized to
@@ -1205,100 +1061,6 @@ __global__ __launch_bounds__(LEAP_GEN_THREADS) void nw_wfa_kernel(const uint4* _
     if (have && !unresolved) out.put(i, result);
 }
 
-// Persistent, lane-refilling form of leap_unit_kernel<K,W64>: a pair needs final_ED+1 generations (mean ~8, max >30
-// at err 0.10); lanes pull the next pair as soon as theirs passes (see greedy_persist_kernel).
-template <int K, int W64>
-__global__ __launch_bounds__(ASM_BLOCK) void leap_unit_persist_kernel(const uint4* __restrict__ planes,
-                                                                      const uint32_t* __restrict__ lens, long n,
-                                                                      int w4, OutMap out,
-                                                                      int refill_min) {
-    constexpr int NL = 2 * K + 1;
-    VW<W64> mask[NL];
-    int en[NL]; /* `end` only: with o == ext the I/D tables are redundant (see leap_unit_pair) */
-    int len = 0, e = 0, result = -1;
-    long idx = -1;
-    bool active = false, finished = true, exhausted = false;
-    WaveQueue wq;
-    wq.init(n);
-#pragma unroll
-    for (int j = 0; j < NL; j++) {
-        en[j] = -2;
-#pragma unroll
-        for (int q = 0; q < W64; q++) mask[j].w[q] = ~0ull;
-    }
-    for (;;) {
-        const bool need = finished && !exhausted;
-        // Refill lazily: the setup below costs about as much as a step, so wait until `refill_min` lanes are idle
-        // (or nothing else is left to do) before paying for it.
-        const unsigned long long need_mask = __ballot(need);
-        if (need_mask != 0ull && (__popcll(need_mask) >= refill_min || __ballot(active && !finished) == 0ull)) {
-            if (need && active) out.put(idx, result);
-            const long got = wq.pull(need);
-            if (need) {
-                idx = got;
-                active = got >= 0;
-                exhausted = !active;
-            }
-            if (need && active) {
-                const uint32_t ln = lens[idx];
-                const int m = (int)(ln & 0xffffu), nn = (int)(ln >> 16);
-                len = m > nn ? m : nn; /* benchmark_utils.h:162 */
-                VW<W64> A0, A1, B0, B1;
-                load_planes<W64>(planes, n, w4, idx, A0, A1, B0, B1);
-                const VW<W64> VA = vw_low_ones<W64>(m), VB = vw_low_ones<W64>(nn);
-#pragma unroll
-                for (int j = 0; j < NL; j++) {
-                    mask[j] = leap_lane_mask<W64>(A0, A1, B0, B1, VA, VB, j - K);
-                    en[j] = -2;
-                }
-                // e = 0: only the main diagonal is live in ED_GLOBAL (LV_BAG.cpp:102-104,131-147)
-                int e0 = vw_next_one<W64>(mask[K], 0);
-                e0 = e0 > len ? len : e0;
-                en[K] = e0;
-                result = -1;
-                e = 0;
-                finished = (e0 == len);
-                if (finished) result = 0;
-            }
-        }
-        if (__ballot(active && !finished) == 0ull) {
-            if (__ballot(active && finished && !exhausted) == 0ull) break;
-            continue; /* some lane finished at e = 0 and must still fetch */
-        }
-        if (active && !finished) {
-            e++;
-            int en2[NL];
-            bool pass = false;
-#pragma unroll
-            for (int j = 0; j < NL; j++) {
-                const int d = j - K;
-                const int top = d >= 0 ? 1 : 0, bot = d <= 0 ? 1 : 0;
-                const int e_up = j > 0 ? en[j - 1] : -2;
-                const int e_dn = j < NL - 1 ? en[j + 1] : -2;
-                int st = en[j] + 1;                     /* LV_BAG.cpp:186-187 */
-                st = e_up + top > st ? e_up + top : st; /* I_pos, :166-176,193-194 */
-                st = e_dn + bot > st ? e_dn + bot : st; /* D_pos, :179-182,200-201 */
-                int enew = -2;
-                if (st >= 0) {
-                    const int from = st > len ? len : st;
-                    int t = vw_next_one<W64>(mask[j], from); /* count_ID_length, :9-23 */
-                    t = t > len ? len : t;
-                    enew = st > len ? st : t;
-                    if (enew == len) { /* :220-238 */
-                        const int diff = d < 0 ? -d : d;
-                        if (e + diff <= ASM_LEAP_AF_THRESHOLD) pass = true;
-                    }
-                }
-                en2[j] = enew;
-            }
-#pragma unroll
-            for (int j = 0; j < NL; j++) en[j] = en2[j];
-            if (pass) result = e, finished = true; /* final_ED (LV_BAG.cpp:228,356-358) */
-            if (e >= ASM_LEAP_AF_THRESHOLD) finished = true;
-        }
-    }
-}
-
 // --------------------------------------------------------------------------------------------------------
 // NW for unit penalties (x = o = e = 1): global edit distance by the Myers/Hyyro bit-parallel recurrence —
 // the column of vertical deltas of the DP matrix lives in bit-vectors, one thread per pair, the read is the
@@ -1715,21 +1477,25 @@ __global__ __launch_bounds__(ASM_BLOCK) void accuracy_kernel(const int32_t* __re
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long stride = (long)gridDim.x * blockDim.x;
     unsigned int c_nw = 0, c_leap = 0, c_greedy = 0;
-    // four pairs per thread and iteration: 16-byte loads, and enough independent loads in flight to cover HBM latency
-    const long n4 = n >> 2;
+    // four pairs per thread and iteration: 16-byte loads, and enough independent loads in flight to cover HBM latency.
+    // Without NW (nw == nullptr) the correct answer of a pair is its entry of the answers file, or nothing (INT32_MIN never
+    // equals a penalty): total_tests still counts every pair.
+    const long n4 = (nw != nullptr || answers != nullptr) ? n >> 2 : 0;
+    const long n_cmp = (nw != nullptr || answers != nullptr) ? n : 0;
     const int4* nw4 = reinterpret_cast<const int4*>(nw);
     const int4* leap4 = reinterpret_cast<const int4*>(leap);
     const int4* greedy4 = reinterpret_cast<const int4*>(greedy);
     const int4* ans4 = reinterpret_cast<const int4*>(answers);
     for (long q = i; q < n4; q += stride) {
-        const int4 p = nw4[q];
+        int4 p = make_int4(INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN);
+        if (nw != nullptr) p = nw4[q];
         int4 want = p;
         if (answers != nullptr) {
             const int4 a = ans4[q];
             want.x = a.x != INT32_MIN ? a.x : p.x, want.y = a.y != INT32_MIN ? a.y : p.y;
             want.z = a.z != INT32_MIN ? a.z : p.z, want.w = a.w != INT32_MIN ? a.w : p.w;
         }
-        c_nw += (p.x == want.x) + (p.y == want.y) + (p.z == want.z) + (p.w == want.w);
+        if (nw != nullptr) c_nw += (p.x == want.x) + (p.y == want.y) + (p.z == want.z) + (p.w == want.w);
         if (leap != nullptr) {
             const int4 l = leap4[q];
             c_leap += (l.x == want.x) + (l.y == want.y) + (l.z == want.z) + (l.w == want.w);
@@ -1739,11 +1505,11 @@ __global__ __launch_bounds__(ASM_BLOCK) void accuracy_kernel(const int32_t* __re
             c_greedy += (g.x == want.x) + (g.y == want.y) + (g.z == want.z) + (g.w == want.w);
         }
     }
-    for (long r = (n4 << 2) + i; r < n; r += stride) { /* the last n mod 4 pairs */
-        const int32_t p = nw[r];
+    for (long r = (n4 << 2) + i; r < n_cmp; r += stride) { /* the last n mod 4 pairs */
+        const int32_t p = nw != nullptr ? nw[r] : INT32_MIN;
         int32_t want = p;
         if (answers != nullptr && answers[r] != INT32_MIN) want = answers[r];
-        c_nw += (p == want) ? 1u : 0u;
+        if (nw != nullptr) c_nw += (p == want) ? 1u : 0u;
         if (leap != nullptr) c_leap += (leap[r] == want) ? 1u : 0u;
         if (greedy != nullptr) c_greedy += (greedy[r] == want) ? 1u : 0u;
     }

@@ -2,7 +2,7 @@
 // wave; at the benchmark's k = 30 that is 61 of 64 lanes busy).  Neighbouring band lanes talk through DPP wave
 // shifts, the wave agrees on "best lane" through DPP max-reductions on order-preserving integer keys, and
 // wave-uniform decisions (termination, the chosen lane) live in scalar registers via __ballot / v_readlane.
-// No LDS, no barriers — the workgroup-per-pair kernels of asm_wide.h remain for k > 31 and for general LEAP penalties.
+// No LDS, no barriers — the workgroup-per-pair kernels of asm_wide.h remain as the fallback.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -44,64 +44,6 @@ ASM_DEV int lane_read(int v, int lane /* wave-uniform */) {
 }
 
 // --------------------------------------------------------------------------------------------------------
-// LEAP, unit penalties, wave per pair.  Same recurrence as leap_unit_kernel (LV::run, LV_BAG.cpp:127-245);
-// lane t of the wave is LEAP lane l = t + 1 (d = t - k), generation e-1 lives in three VGPRs per lane.
-// --------------------------------------------------------------------------------------------------------
-template <int W64>
-__global__ __launch_bounds__(ASM_BLOCK) void leap_wave_kernel(const uint4* __restrict__ planes,
-                                                              const uint32_t* __restrict__ lens, long n, int w4,
-                                                              int k, OutMap out) {
-    const int t = threadIdx.x & 63;
-    const long wave0 = __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
-    const int nl = 2 * k + 1;
-    const bool active = t < nl;
-    const int d = t - k;
-    const int diff = d < 0 ? -d : d;
-    const int top = d >= 0 ? 1 : 0, bot = d <= 0 ? 1 : 0;
-    for (long i = wave0; i < n; i += nwaves) {
-        const uint32_t ln = lens[i];
-        const int m = (int)(ln & 0xffffu), nn = (int)(ln >> 16);
-        const int len = m > nn ? m : nn; /* benchmark_utils.h:162 */
-        VW<W64> A0, A1, B0, B1;
-        load_planes<W64>(planes, n, w4, i, A0, A1, B0, B1);
-        const VW<W64> VA = vw_low_ones<W64>(m), VB = vw_low_ones<W64>(nn);
-        VW<W64> mask = leap_lane_mask<W64>(A0, A1, B0, B1, VA, VB, active ? d : 0);
-        int en = -2, result = -1; /* `end` only: with o == ext the I/D tables are redundant (see leap_unit_pair) */
-        if (t == k) { /* e = 0: main diagonal only (LV_BAG.cpp:102-104,131-147) */
-            int e0 = vw_next_one<W64>(mask, 0);
-            en = e0 > len ? len : e0;
-        }
-        if (__ballot(t == k && en == len) != 0ull) {
-            result = 0;
-        } else {
-            for (int e = 1; e <= ASM_LEAP_AF_THRESHOLD; e++) {
-                const int e_up = wave_from_below(en, -2), e_dn = wave_from_above(en, -2);
-                int st = en + 1;                        /* LV_BAG.cpp:186-187 */
-                st = e_up + top > st ? e_up + top : st; /* I_pos, :166-176,193-194 */
-                st = e_dn + bot > st ? e_dn + bot : st; /* D_pos, :179-182,200-201 */
-                int enew = -2;
-                bool pass = false;
-                if (active && st >= 0) {
-                    const int from = st > len ? len : st;
-                    int r = vw_next_one<W64>(mask, from); /* count_ID_length, :9-23 */
-                    r = r > len ? len : r;
-                    enew = st > len ? st : r;
-                    pass = enew == len && e + diff <= ASM_LEAP_AF_THRESHOLD; /* :220-238 */
-                }
-                /* lanes outside the band stay at -2 so that they look like the reference's sentinel lanes */
-                en = enew;
-                if (__ballot(pass) != 0ull) {
-                    result = e; /* final_ED (LV_BAG.cpp:228,356-358) */
-                    break;
-                }
-            }
-        }
-        if (t == 0) out.put(i, result);
-    }
-}
-
-// --------------------------------------------------------------------------------------------------------
 // Work distribution of the wave-per-pair kernels.  Their grid is sized to what is resident when the kernel runs alone; in
 // asm_run_benchmark_async they run beside another aligner's kernel and only part of the grid is resident at first, so a
 // static "wave w takes pairs w, w + W, ..." split leaves the late workgroups a full share to do after everybody else has
@@ -132,14 +74,11 @@ struct PairQueue {
 };
 
 // --------------------------------------------------------------------------------------------------------
-// LEAP, unit penalties, wide band, ONE THREAD PER PAIR with the band in LDS.  In generation e only the lanes |d| <= e can
-// be live, so a wave-per-pair mapping keeps a third of its lanes busy at k = 30 (final_ED ~ 20); here a thread sweeps
-// exactly the live lanes of its own pair.  The lane's `end` values (one int16 per lane, updated in place: the sweep
-// carries the old values of lanes l-1 and l in registers) and the pair's bit planes live in thread-private LDS columns
-// ([row][thread]: conflict-free, no barriers); the lane mask is not materialised — count_ID_length (LV_BAG.cpp:9-23)
-// compares a 32-position window of the read with the window of the reference the lane pairs it with, cut out of the
-// planes with v_alignbit_b32, and stops at the first difference or where either string ends.
-// Same recurrence and results as leap_unit_pair / leap_wave_kernel (LV::run, LV_BAG.cpp:127-245).
+// count_ID_length (LV_BAG.cpp:9-23) on bit planes held in LDS, shared by the wide-band kernels below: a lane mask is not
+// materialised — a 32-position window of the read is compared with the window of the reference the lane pairs it with, both
+// cut out of the planes with v_alignbit_b32, until the first difference or where either string ends.
+// (The thread-per-pair forms that first used these helpers, leap_band_kernel / leap_band_general_kernel, and the wave-per-pair
+// leap_wave_kernel lost to the four-threads-per-pair kernel everywhere and were removed in round 4; DESIGN.md keeps their numbers.)
 // --------------------------------------------------------------------------------------------------------
 #define LEAP_BAND_THREADS 128
 
@@ -171,221 +110,6 @@ ASM_DEV int leap_band_extend(const uint32_t* pl, int d, int from, int m, int nn)
     return p < lim ? p : lim;
 }
 
-template <int W32, typename EnT> /* plane dwords per string kept in LDS; EnT = int8_t-like storage when every position fits */
-__global__ __launch_bounds__(LEAP_BAND_THREADS) void leap_band_kernel(const uint4* __restrict__ planes,
-                                                                      const uint32_t* __restrict__ lens, long n, int w4,
-                                                                      int k, OutMap out) {
-    constexpr int T = LEAP_BAND_THREADS, PD = W32 + 1;
-    extern __shared__ uint32_t s_band[];
-    uint32_t* const pl = s_band + threadIdx.x;                                   /* [4][PD][T] */
-    EnT* const en = reinterpret_cast<EnT*>(s_band + 4 * PD * T) + threadIdx.x; /* [2k+4][T]: lane l at row l+1, guards 0 and 2k+2;
-                                                                                   stored value = end + 2 (0 = never reached) */
-    const long i = (long)blockIdx.x * T + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t ln = lens[i];
-    const int m = (int)(ln & 0xffffu), nn = (int)(ln >> 16);
-    const int len = m > nn ? m : nn; /* benchmark_utils.h:162 */
-#pragma unroll
-    for (int g = 0; g < (W32 + 3) / 4; g++) {
-#pragma unroll
-        for (int pln = 0; pln < 4; pln++) {
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (g < w4) v = planes[((long)pln * w4 + g) * n + i];
-            uint32_t* dst = pl + (pln * PD + 4 * g) * T;
-            dst[0] = v.x;
-            if (4 * g + 1 < W32) dst[T] = v.y;
-            if (4 * g + 2 < W32) dst[2 * T] = v.z;
-            if (4 * g + 3 < W32) dst[3 * T] = v.w;
-        }
-    }
-#pragma unroll
-    for (int pln = 0; pln < 4; pln++) pl[(pln * PD + W32) * T] = 0u;
-    const int rows = 2 * k + 4; /* lanes 0..2k at rows 1..2k+1, guard rows 0 and 2k+2, one spare row for the look-ahead read */
-    for (int l = 0; l < rows; l++) en[l * T] = (EnT)0;
-    int result = -1;
-    {   /* e = 0: main diagonal only (LV_BAG.cpp:102-104,131-147) */
-        int e0 = leap_band_extend<PD>(pl, 0, 0, m, nn);
-        e0 = e0 > len ? len : e0;
-        en[(k + 1) * T] = (EnT)(e0 + 2);
-        if (e0 == len) result = 0;
-    }
-    for (int e = 1; e <= ASM_LEAP_AF_THRESHOLD; e++) {
-        if (__ballot(result < 0) == 0ull) break;
-        if (result < 0) {
-            const int lo = k - e > 0 ? k - e : 0, hi = k + e < 2 * k ? k + e : 2 * k;
-            int up_old = (int)en[lo * T] - 2, cur_old = (int)en[(lo + 1) * T] - 2;
-            int dn_old = (int)en[(lo + 2) * T] - 2;
-            bool pass = false;
-            for (int l = lo; l <= hi; l++) {
-                /* the next lane's old value is fetched before this lane's extension, so its LDS latency hides behind it
-                 * (row 2k+3 is a spare guard row the last lane reads and nobody uses) */
-                const int dn_next = (int)en[(l + 3) * T] - 2;
-                const int d = l - k;
-                const int top = d >= 0 ? 1 : 0, bot = d <= 0 ? 1 : 0;
-                int st = cur_old + 1;                         /* LV_BAG.cpp:186-187 */
-                st = up_old + top > st ? up_old + top : st;   /* I_pos (redundant table at o = ext, see leap_unit_pair) */
-                st = dn_old + bot > st ? dn_old + bot : st;   /* D_pos */
-                int enew = -2;
-                if (st >= 0) {
-                    const int from = st > len ? len : st;
-                    int r = leap_band_extend<PD>(pl, d, from, m, nn); /* count_ID_length, :9-23 */
-                    r = r > len ? len : r;
-                    enew = st > len ? st : r;
-                    const int diff = d < 0 ? -d : d;
-                    if (enew == len && e + diff <= ASM_LEAP_AF_THRESHOLD) pass = true; /* :220-238 */
-                }
-                en[(l + 1) * T] = (EnT)(enew + 2);
-                up_old = cur_old, cur_old = dn_old, dn_old = dn_next;
-            }
-            if (pass) result = e; /* final_ED (LV_BAG.cpp:228,356-358) */
-        }
-    }
-    out.put(i, result);
-}
-
-static inline size_t leap_band_lds(int w32, int k, size_t en_bytes) {
-    return (size_t)4 * (w32 + 1) * LEAP_BAND_THREADS * sizeof(uint32_t) + (((size_t)(2 * k + 4) * LEAP_BAND_THREADS * en_bytes + 3) & ~(size_t)3);
-}
-
-template <int W32, typename EnT>
-static inline hipError_t launch_leap_band(hipStream_t stream, const uint4* planes, const uint32_t* lens, int64_t n, int w4, int k,
-                                          OutMap out) {
-    const dim3 grid((unsigned)((n + LEAP_BAND_THREADS - 1) / LEAP_BAND_THREADS)), block(LEAP_BAND_THREADS);
-    hipLaunchKernelGGL((leap_band_kernel<W32, EnT>), grid, block, leap_band_lds(W32, k, sizeof(EnT)), stream, planes, lens,
-                       (long)n, w4, k, out);
-    return hipGetLastError();
-}
-
-// --------------------------------------------------------------------------------------------------------
-// LEAP, general penalties (x, o, ext), wide band: the thread-per-pair form of leap_band_kernel with the generation
-// rings of leap_general_kernel — `end` over gm = 2^a > max(x, o) generations, I and D over gi = 2^b > ext — as bytes or
-// shorts in thread-private LDS columns [ring slot][lane row][thread].  Lane d can only be live once a gap of |d| is
-// affordable, e >= o + (|d|-1) ext, so generation e sweeps |d| <= dmax(e); dmax never shrinks, hence whatever a slot
-// still holds beyond it from gm generations earlier is the "never reached" code and nothing needs clearing after the
-// initial zero fill (0 = -2: values are stored +2).
-// --------------------------------------------------------------------------------------------------------
-#define LEAP_BANDG_THREADS 64
-template <int W32, typename EnT>
-__global__ __launch_bounds__(LEAP_BANDG_THREADS) void leap_band_general_kernel(const uint4* __restrict__ planes,
-                                                                               const uint32_t* __restrict__ lens, long n, int w4,
-                                                                               int k, int x, int o, int ext, int gm, int gi,
-                                                                               OutMap out) {
-    constexpr int T = LEAP_BANDG_THREADS, PD = W32 + 1;
-    static_assert(LEAP_BANDG_THREADS == 64 && LEAP_BAND_THREADS == 128, "leap_band_window strides by LEAP_BAND_THREADS");
-    extern __shared__ uint32_t s_band[];
-    const int rows = 2 * k + 3; /* lane l at row l+1, guard rows 0 and 2k+2 */
-    const int slot = rows * T;  /* elements per ring slot */
-    // planes use the stride of leap_band_window (LEAP_BAND_THREADS): two blocks' worth of columns, this block uses the first 64
-    uint32_t* const pl = s_band + threadIdx.x;                                        /* [4][PD][LEAP_BAND_THREADS] */
-    EnT* const r_en = reinterpret_cast<EnT*>(s_band + 4 * PD * LEAP_BAND_THREADS) + threadIdx.x; /* [gm][rows][T] */
-    EnT* const r_ip = r_en + gm * slot;                                               /* [gi][rows][T] */
-    EnT* const r_dp = r_ip + gi * slot;
-    {   /* zero fill of all rings by the whole block */
-        const int words = (int)(((size_t)(gm + 2 * gi) * slot * sizeof(EnT) + 3) / 4);
-        uint32_t* const base = s_band + 4 * PD * LEAP_BAND_THREADS;
-        for (int q = threadIdx.x; q < words; q += T) base[q] = 0u;
-    }
-    __syncthreads();
-    const long i = (long)blockIdx.x * T + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t ln = lens[i];
-    const int m = (int)(ln & 0xffffu), nn = (int)(ln >> 16);
-    const int len = m > nn ? m : nn; /* benchmark_utils.h:162 */
-#pragma unroll
-    for (int g = 0; g < (W32 + 3) / 4; g++) {
-#pragma unroll
-        for (int pln = 0; pln < 4; pln++) {
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (g < w4) v = planes[((long)pln * w4 + g) * n + i];
-            uint32_t* dst = pl + (pln * PD + 4 * g) * LEAP_BAND_THREADS;
-            dst[0] = v.x;
-            if (4 * g + 1 < W32) dst[LEAP_BAND_THREADS] = v.y;
-            if (4 * g + 2 < W32) dst[2 * LEAP_BAND_THREADS] = v.z;
-            if (4 * g + 3 < W32) dst[3 * LEAP_BAND_THREADS] = v.w;
-        }
-    }
-#pragma unroll
-    for (int pln = 0; pln < 4; pln++) pl[(pln * PD + W32) * LEAP_BAND_THREADS] = 0u;
-    int result = -1;
-    {   /* e = 0: main diagonal only (LV_BAG.cpp:102-104,131-147) */
-        int e0 = leap_band_extend<PD>(pl, 0, 0, m, nn);
-        e0 = e0 > len ? len : e0;
-        r_en[(k + 1) * T] = (EnT)(e0 + 2);
-        if (e0 == len) result = 0;
-    }
-    for (int e = 1; e <= ASM_LEAP_AF_THRESHOLD; e++) {
-        if (__ballot(result < 0) == 0ull) break;
-        if (result < 0) {
-            int dmax = e < o ? 0 : (e - o) / ext + 1;
-            dmax = dmax > k ? k : dmax;
-            const EnT* const en_o = r_en + ((e - o) & (gm - 1)) * slot;
-            const EnT* const en_x = r_en + ((e - x) & (gm - 1)) * slot;
-            const EnT* const ip_e = r_ip + ((e - ext) & (gi - 1)) * slot;
-            const EnT* const dp_e = r_dp + ((e - ext) & (gi - 1)) * slot;
-            EnT* const en_w = r_en + (e & (gm - 1)) * slot;
-            EnT* const ip_w = r_ip + (e & (gi - 1)) * slot;
-            EnT* const dp_w = r_dp + (e & (gi - 1)) * slot;
-            // no e >= o / e >= x / e >= ext guards: the slot of a generation before 0 is one not written yet, still zero
-            bool pass = false;
-            for (int l = k - dmax; l <= k + dmax; l++) {
-                const int d = l - k;
-                const int top = d >= 0 ? 1 : 0, bot = d <= 0 ? 1 : 0;
-                const int e_up = (int)en_o[l * T] - 2;       /* lane l-1 sits at row l */
-                const int i_up = (int)ip_e[l * T] - 2;
-                const int e_dn = (int)en_o[(l + 2) * T] - 2; /* lane l+1 */
-                const int d_dn = (int)dp_e[(l + 2) * T] - 2;
-                const int own = (int)en_x[(l + 1) * T] - 2;
-                int inew = -2, dnew = -2;
-                if (e_up >= 0 && e_up > i_up)
-                    inew = e_up + top; /* LV_BAG.cpp:166-167 */
-                else if (i_up >= 0)
-                    inew = i_up + top; /* :172-176 */
-                if (e_dn >= 0 && e_dn > d_dn)
-                    dnew = e_dn + bot; /* :179-180 */
-                else if (d_dn >= 0)
-                    dnew = d_dn + bot; /* :181-182 */
-                int st = own >= 0 ? own + 1 : -2; /* :186-187 */
-                st = inew > st ? inew : st;
-                st = dnew > st ? dnew : st;
-                int enew = -2;
-                if (st >= 0) {
-                    const int from = st > len ? len : st;
-                    int r = leap_band_extend<PD>(pl, d, from, m, nn); /* count_ID_length, :9-23 */
-                    r = r > len ? len : r;
-                    enew = st > len ? st : r;
-                    if (enew == len) { /* :220-238 */
-                        const int diff = d < 0 ? -d : d;
-                        const int conv = e + (diff ? o + (diff - 1) * ext : 0);
-                        if (conv <= ASM_LEAP_AF_THRESHOLD) pass = true;
-                    }
-                }
-                en_w[(l + 1) * T] = (EnT)(enew + 2), ip_w[(l + 1) * T] = (EnT)(inew + 2), dp_w[(l + 1) * T] = (EnT)(dnew + 2);
-            }
-            if (pass) result = e; /* final_ED (LV_BAG.cpp:228,356-358) */
-        }
-    }
-    out.put(i, result);
-}
-
-static inline size_t leap_band_general_lds(int w32, int k, int gm, int gi, size_t en_bytes) {
-    return (size_t)4 * (w32 + 1) * LEAP_BAND_THREADS * sizeof(uint32_t) +
-           (((size_t)(gm + 2 * gi) * (2 * k + 3) * LEAP_BANDG_THREADS * en_bytes + 3) & ~(size_t)3);
-}
-
-template <int W32, typename EnT>
-static inline hipError_t launch_leap_band_general(hipStream_t stream, const uint4* planes, const uint32_t* lens, int64_t n, int w4,
-                                                  int k, int x, int o, int e, int gm, int gi, OutMap out) {
-    const dim3 grid((unsigned)((n + LEAP_BANDG_THREADS - 1) / LEAP_BANDG_THREADS)), block(LEAP_BANDG_THREADS);
-    const size_t lds = leap_band_general_lds(W32, k, gm, gi, sizeof(EnT));
-    if (lds > 64 * 1024) { /* deep rings at a wide band (e.g. (4,6,2) at k = 30): a CU's 160 KB still hold two such workgroups */
-        const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&leap_band_general_kernel<W32, EnT>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e2 != hipSuccess) return e2;
-    }
-    hipLaunchKernelGGL((leap_band_general_kernel<W32, EnT>), grid, block, lds, stream, planes, lens, (long)n, w4, k, x, o, e, gm, gi, out);
-    return hipGetLastError();
-}
-
 // --------------------------------------------------------------------------------------------------------
 // LEAP, wide band, FOUR THREADS PER PAIR (a quad), sixteen pairs per wave.  Within one generation the lanes are independent —
 // `end`, I and D of generation e read generations e-o, e-x and e-ext only — so the live lanes of a pair are dealt round-robin to
@@ -397,7 +121,7 @@ static inline hipError_t launch_leap_band_general(hipStream_t stream, const uint
 // slots are enough (I and D are redundant at o == ext, see leap_unit_pair).  A wave's LDS operations complete in program
 // order, so the only synchronisation between generations is a wave-scope fence that keeps the compiler from moving a read
 // of another thread's value above the writes of the generation before.
-// Same recurrences and results as leap_band_kernel / leap_band_general_kernel (LV::run, LV_BAG.cpp:127-245).
+// Same recurrences and results as leap_unit_kernel / leap_general_kernel (LV::run, LV_BAG.cpp:127-245).
 // Measured and dropped: a persistent form with decoupled quads (every quad at its own generation, one lane per thread per
 // trip of the wave's loop, a quad whose pair has passed takes the next pair from a device-memory queue) — it removes the wait
 // for the slowest of the sixteen pairs (work grows with final_ED^2: ~1.6x the mean at C3), was bit-identical, and ran 1.31 ms

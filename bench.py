@@ -172,7 +172,20 @@ def parse_args():
                     help="N > 1 only: TOTAL pairs of the two extra legs (BASELINE configs 4 and 5: C4 strong scaling, C5 bucketed)")
     ap.add_argument("--extra-steps", type=int, default=5)
     ap.add_argument("--no-extra", action="store_true", help="N > 1: skip the C4 / C5 legs")
+    ap.add_argument("--rotate", type=int, default=0,
+                    help="resident batches the timed steps rotate over (step s uses batch s mod R), so that no step finds its "
+                         "input in the 256 MiB Infinity Cache where an earlier step left it; 0 = as many as it takes for the "
+                         "ASCII of R batches to exceed 1 GiB (6 at C2), 1 = one batch re-read every step")
     return ap.parse_args()
+
+
+LLC_BYTES = 256 << 20  # MI355X Infinity Cache (MI355X_MICROARCH.md): what a re-read working set must exceed to come from HBM
+
+
+def default_rotation(ascii_bytes):
+    """Batches to rotate over: enough that their ASCII alone is 4x the Infinity Cache (the packed planes and the penalty arrays
+    come on top), at most 8; a batch that is already that large is not rotated."""
+    return int(max(1, min(8, -(-4 * LLC_BYTES // max(int(ascii_bytes), 1)))))
 
 
 def free_port():
@@ -273,6 +286,15 @@ def main():
 
 def run(args, asm, eng, torch, dist, stream, rank, world, cfg, params, first, n, coll_device):
     batch = eng.generate(cfg, first, n)  # this rank's shard of the seeded stream, straight into HBM
+    # The reference reads every pair once (benchmark_utils.h:373-385); a bench that re-packs ONE resident batch K times reads a
+    # 350 MB working set that partly survives in the Infinity Cache from step to step.  So the timed steps rotate over R
+    # distinct resident batches of the same seeded stream (batch j of rank r = the shard rank r would own in job j): step s
+    # reads batch s mod R, whose ASCII, planes and outputs were last touched R steps — more than 1 GiB of traffic — ago.
+    rot = args.rotate or default_rotation(batch.ascii_bytes)
+    batches = [batch]
+    for j in range(1, rot):
+        fj = first + j * args.total_pairs if args.total_pairs else asm.weak_shard_first(rank + j * world, n)
+        batches.append(eng.generate(cfg, fj, n))
     aligners = [asm.NW, asm.LEAP, asm.GREEDY] if args.workload != "C3" else [asm.LEAP, asm.GREEDY]
     d_pen = {a: eng.malloc(4 * n) for a in aligners}
     counters = torch.zeros(4, dtype=torch.int64, device="cuda")  # total, nw_ok, leap_ok, greedy_ok
@@ -281,8 +303,12 @@ def run(args, asm, eng, torch, dist, stream, rank, world, cfg, params, first, n,
     # overlapped calls (repack = 3) alternate between two sets of output arrays
     d_alt = {a: eng.malloc(4 * n) for a in aligners} if PACK_MODE == 3 else d_pen
     calls = [0]
+    it = [0]  # steps issued since the last reset: which batch is next
 
-    def step(timers=None, b=batch, repack=True):
+    def step(timers=None, b=None, repack=True):
+        if b is None:
+            b = batches[it[0] % len(batches)]
+            it[0] += 1
         if timers is None:
             # `_run_benchmark` for the whole batch: pack, aligners, counters — one C-ABI call, five launches
             if PACK_MODE == 3 and repack:
@@ -309,7 +335,7 @@ def run(args, asm, eng, torch, dist, stream, rank, world, cfg, params, first, n,
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, len(batches))):  # every batch is packed (and its second plane set allocated) once
         step()
     eng.pipeline_join_async()
     # stand-alone durations: a separately instrumented pass with the kernels one after the other on one stream (what a
@@ -322,6 +348,12 @@ def run(args, asm, eng, torch, dist, stream, rank, world, cfg, params, first, n,
     eng.synchronize()
     kernel_ms = {k: float(np.mean([t.elapsed_ms() for t in v])) for k, v in timers.items()}
     dom = max(kernel_ms, key=kernel_ms.get)
+    same_timers = {}
+    if len(batches) > 1 and not args.no_standalone:  # the same pass over ONE batch: what the Infinity Cache gives a re-read
+        for _ in range(min(args.steps, 20)):
+            step(same_timers, b=batch)
+        eng.synchronize()
+    kernel_ms_same = {k: float(np.mean([t.elapsed_ms() for t in v])) for k, v in same_timers.items()}
     if dist is not None:  # warm the collective up outside the timed region (RCCL builds its rings on first use)
         dist.all_reduce(torch.zeros(4, dtype=torch.int64, device=coll_device))
     barrier()
@@ -332,6 +364,7 @@ def run(args, asm, eng, torch, dist, stream, rank, world, cfg, params, first, n,
     eng.profile_enable(args.steps, 1 << names.index(dom))
     ev_ar = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     torch.cuda.synchronize()
+    it[0] = 0  # timed step s reads batch s mod R
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -368,17 +401,51 @@ def run(args, asm, eng, torch, dist, stream, rank, world, cfg, params, first, n,
     q_dom = names.index(dom)
     region_ms = {dom: float(region[:, q_dom].mean())} if region.shape[0] and (region[:, q_dom] >= 0).all() else {dom: kernel_ms[dom]}
 
+    # what the counters must be: one in-order pass per batch gives that batch's four counts c_j; the timed region used batch j
+    # in uses_j of its steps, so counters == sum_j uses_j * c_j exactly (tests/test_gpu_bench.py checks c_j against the oracle)
+    uses = [len(range(j, args.steps, len(batches))) for j in range(len(batches))]
+    expected = torch.zeros(4, dtype=torch.int64, device="cuda")
+    per_batch = []
+    for j, bj in enumerate(batches):
+        cj = torch.zeros(4, dtype=torch.int64, device="cuda")
+        eng.run_benchmark_async(bj, params, d_nw, d_leap, d_greedy, cj.data_ptr(), repack=1)
+        eng.synchronize()
+        per_batch.append([int(v) for v in cj.cpu().numpy()])
+        expected += uses[j] * cj
+    if dist is not None:
+        if coll_device.type == "cuda":
+            dist.all_reduce(expected)
+        else:
+            host = expected.cpu()
+            dist.all_reduce(host)
+            expected.copy_(host)
+    expected = [int(v) for v in expected.cpu().numpy()]
+
     # the same K steps strictly in order (repack = 1), for the record: what a caller without a second batch in flight gets
     in_order_ms = None
+    scratch_cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
     if PACK_MODE != 1 and not args.no_in_order:
-        scratch_cnt = torch.zeros(4, dtype=torch.int64, device="cuda")
         k_in = min(args.steps, 20)
         barrier()
         t1 = time.perf_counter()
-        for _ in range(k_in):
-            eng.run_benchmark_async(batch, params, d_nw, d_leap, d_greedy, scratch_cnt.data_ptr(), repack=1)
+        for s_ in range(k_in):
+            eng.run_benchmark_async(batches[s_ % len(batches)], params, d_nw, d_leap, d_greedy, scratch_cnt.data_ptr(), repack=1)
         barrier()
         in_order_ms = (time.perf_counter() - t1) / k_in * 1e3
+    # ... and the headline's form of the steps over ONE batch (what rounds 1-3 timed): the Infinity Cache's share of the number
+    same_batch_ms = None
+    if len(batches) > 1 and not args.no_in_order:
+        k_in = min(args.steps, 20)
+        for _ in range(2):
+            step(b=batch)
+        eng.pipeline_join_async()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(k_in):
+            step(b=batch)
+        eng.pipeline_join_async()
+        barrier()
+        same_batch_ms = (time.perf_counter() - t1) / k_in * 1e3
 
     sequential = None
     if not args.no_sequential and asm.GREEDY in aligners:
@@ -401,7 +468,7 @@ def run(args, asm, eng, torch, dist, stream, rank, world, cfg, params, first, n,
     if rank != 0:
         return None
     # leave the penalties of the CLEAN-mode batch in d_pen for the parity leg below
-    step(repack=False)
+    step(b=batch, repack=False)
     eng.synchronize()
     total_pairs = (args.total_pairs if args.total_pairs else world * n) * args.steps
     value = total_pairs / elapsed
@@ -434,9 +501,16 @@ def run(args, asm, eng, torch, dist, stream, rank, world, cfg, params, first, n,
                         + "+".join(asm.ALIGNER_NAMES[a] for a in aligners) + ", greedy tails=clean",
             "pairs_per_gpu": n,
             "sharding": "independent pairs, contiguous shard per rank, one 32-byte all-reduce of counters",
-            "steps_run": STEP_FORMS[PACK_MODE],
+            "steps_run": STEP_FORMS[steps_form(asm, aligners, params)],
+            "rotation": f"{len(batches)} resident batches of {n} pairs, step s reads batch s mod {len(batches)} "
+                        f"({len(batches) * batch.ascii_bytes / 2**20:.0f} MiB of ASCII against a 256 MiB Infinity Cache)",
         },
         "ms_per_step_in_order": in_order_ms,
+        "ms_per_step_same_batch": same_batch_ms,
+        "pack_GBps": {"rotating": pack_gbps(batch, n, kernel_ms.get("pack")),
+                      "same_batch": pack_gbps(batch, n, kernel_ms_same.get("pack")),
+                      "bytes": "ASCII read + 68 B of planes and lengths written per pair"},
+        "kernel_ms_same_batch": kernel_ms_same or None,
         "ms_per_step_per_rank": per_rank_ms,
         "allreduce_ms": allreduce_ms,
         "kernel_ms_in_timed_region": region_ms,
@@ -446,7 +520,9 @@ def run(args, asm, eng, torch, dist, stream, rank, world, cfg, params, first, n,
         "accuracy_pct": {asm.ALIGNER_NAMES[a]: 100.0 * float(cnt[1 + a]) / float(cnt[0]) for a in aligners}
         if asm.NW in aligners else None,
         "counters": {"total": int(cnt[0]), "nw_ok": int(cnt[1]), "leap_ok": int(cnt[2]), "greedy_ok": int(cnt[3]),
-                     "expected_total": (args.total_pairs if args.total_pairs else world * n) * args.steps},
+                     "expected_total": (args.total_pairs if args.total_pairs else world * n) * args.steps,
+                     "expected": expected, "as_expected": [int(v) for v in cnt] == expected,
+                     "per_batch_single_pass_rank0": per_batch, "steps_per_batch": uses},
         "coverage_pct": coverage,
         "sequential_mode": sequential,
         **(extra or {}),
@@ -474,6 +550,22 @@ def run(args, asm, eng, torch, dist, stream, rank, world, cfg, params, first, n,
     return out
 
 
+def pack_gbps(batch, n, ms):
+    """pack_kernel's bytes per launch (ASCII in, 4 x 16-byte plane granules + 4 bytes of lengths out at <= 128 characters) over
+    its stand-alone duration."""
+    if not ms:
+        return None
+    return (batch.ascii_bytes + 68.0 * n) / (ms * 1e-3) / 1e9
+
+
+def steps_form(asm, aligners, params):
+    """The form asm_run_benchmark_async really runs: a call with the Greedy-first shape (LEAP + Greedy without NW at a wide
+    band, i.e. C3) asked to overlap runs as a pipelined-pack call."""
+    if PACK_MODE == 3 and asm.NW not in aligners and params.k > 5:
+        return 2
+    return PACK_MODE
+
+
 def extra_leg(args, asm, eng, torch, dist, stream, rank, world, workload, coll_device, barrier):
     """One more configuration of BASELINE.json in the same N-rank job: `--extra-pairs` pairs IN TOTAL (strong scaling), rank r
     owns the contiguous slice asm.shard_bounds gives it, generated on its own GPU; step = pack + NW + LEAP + Greedy + counters as
@@ -484,6 +576,9 @@ def extra_leg(args, asm, eng, torch, dist, stream, rank, world, workload, coll_d
     lo, hi = asm.shard_bounds(total, world, rank)
     n = hi - lo
     batch = eng.generate(cfg, lo, n)
+    # rotating inputs as in the main line: batch j of this rank = its slice of the j-th block of `total` pairs of the stream
+    rot = args.rotate or default_rotation(batch.ascii_bytes)
+    batches = [batch] + [eng.generate(cfg, lo + j * total, n) for j in range(1, rot)]
     d = [eng.malloc(4 * max(n, 1)) for _ in range(6 if PACK_MODE == 3 else 3)]
     counters = torch.zeros(4, dtype=torch.int64, device="cuda")
     steps = args.extra_steps
@@ -491,14 +586,17 @@ def extra_leg(args, asm, eng, torch, dist, stream, rank, world, workload, coll_d
 
     def step():
         o = d[3:] if (PACK_MODE == 3 and calls[0] & 1) else d[:3]
+        b = batches[calls[0] % rot]
         calls[0] += 1
-        eng.run_benchmark_async(batch, params, o[0], o[1], o[2], counters.data_ptr(), repack=PACK_MODE)
+        eng.run_benchmark_async(b, params, o[0], o[1], o[2], counters.data_ptr(), repack=PACK_MODE)
 
-    step()
+    for _ in range(rot):
+        step()
     eng.pipeline_join_async()
     barrier()
     counters.zero_()
     torch.cuda.synchronize()
+    calls[0] = 0
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -527,10 +625,12 @@ def extra_leg(args, asm, eng, torch, dist, stream, rank, world, workload, coll_d
     cnt = counters.cpu().numpy()
     for ptr in d:
         eng.free(ptr)
-    batch.free()
+    for b in batches:
+        b.free()
     return {
         "workload": f"{workload}: {total} pairs in total over {world} ranks (strong), len {cfg.len_lo}-{cfg.len_hi}, "
-                    f"{edit_model(asm, cfg)}, k={params.k}" + (", bucketed by length inside each rank" if cfg.len_hi > cfg.len_lo else ""),
+                    f"{edit_model(asm, cfg)}, k={params.k}" + (", bucketed by length inside each rank" if cfg.len_hi > cfg.len_lo else "")
+                    + f", rotating over {rot} resident batches",
         "scaling": "strong",
         "steps": steps,
         "ms_per_step": elapsed / steps * 1e3,

@@ -158,6 +158,8 @@ int asm_batch_free(asm_handle* h, asm_batch* b); /* the device blocks go back to
                                                     destroyed its device memory went with it and only the record is freed */
 int64_t asm_batch_size(const asm_batch* b);
 int asm_batch_max_length(const asm_batch* b);
+/* bytes of resident ASCII (reads + references) */
+int64_t asm_batch_text_bytes(const asm_batch* b);
 /* Copies the batch's ASCII form back to the host (buffers sized by the caller from the offsets). */
 int asm_batch_download(asm_handle* h, const asm_batch* b, uint32_t* read_off, uint32_t* ref_off,
                        char* reads, size_t reads_cap, char* refs, size_t refs_cap);
@@ -285,7 +287,8 @@ int asm_count_equal_async(asm_handle* h, const int32_t* d_a, const int32_t* d_b,
 /* All counters of `_run_benchmark` (benchmark_utils.h:238,249-255) in one pass over device penalty arrays:
  * d_counters[0..3] += {total_tests, nw_correct, LEAP_correct, greedy_correct}; the correct answer of pair i is
  * d_answers[i] when d_answers is given and != INT32_MIN (read_answer_file, benchmark_utils.h:358-368), else the NW
- * penalty.  d_leap / d_greedy / d_answers may be NULL.  Enqueue only. */
+ * penalty.  d_nw / d_leap / d_greedy / d_answers may be NULL; without d_nw a pair has a correct answer only where the
+ * answers file gives one, and total_tests counts every pair regardless.  Enqueue only. */
 int asm_accuracy_async(asm_handle* h, const int32_t* d_nw, const int32_t* d_leap, const int32_t* d_greedy,
                        const int32_t* d_answers, int64_t n, unsigned long long* d_counters);
 /* `_run_benchmark` for a whole resident batch in one call (benchmark_utils.h:231-259): optional re-pack of the

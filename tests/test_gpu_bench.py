@@ -25,23 +25,27 @@ def _bench(extra_env, *argv, expect_ok=True):
     return json.loads(lines[0])
 
 
-def _expected_counts(asm, oracle, first, n):
-    cfg, _, params = asm.workload("C2")
+def _expected_counts(asm, oracle, first, n, wl="C2"):
+    cfg, _, params = asm.workload(wl)
     hb = asm.generate_pairs(cfg, first, n)
     nw, leap, greedy = oracle.nw(hb), oracle.leap(hb, params.k), oracle.greedy(hb, params.k, mode=1)
     return np.array([n, n, int((leap == nw).sum()), int((greedy == nw).sum())])
 
 
 def test_self_started_ranks_share_one_stream_with_the_collective(asm, oracle):
-    n, steps = 20000, 3
+    n, steps, rot = 20000, 4, 3
     extra_total, extra_steps = 30001, 2   # an odd total: the strong split gives the ranks different shard sizes
-    out = _bench({"ASM_DIST_BACKEND": "gloo"}, "--gpus", "2", "--pairs", str(n), "--steps", str(steps), "--warmup", "1",
+    out = _bench({"ASM_DIST_BACKEND": "gloo"}, "--gpus", "2", "--pairs", str(n), "--steps", str(steps), "--warmup", "1", "--rotate", str(rot),
                  "--cpu-sample", "20000", "--no-cpu-baseline", "--extra-pairs", str(extra_total), "--extra-steps", str(extra_steps))
     assert out["n_gpus"] == 2 and len(out["ms_per_step_per_rank"]) == 2 and out["allreduce_ms"] is not None
-    want = steps * (_expected_counts(asm, oracle, 0, n) + _expected_counts(asm, oracle, n, n))   # rank r owns [r*n, (r+1)*n)
+    # rotating inputs: step s of rank r reads batch s mod R, batch j of rank r = shard r + j * world of the seeded stream, so the
+    # counters are the oracle's counts of shards 0..5, shards 0 and 1 (used by steps 0 and 3) twice
+    shard = [_expected_counts(asm, oracle, q * n, n) for q in range(2 * rot)]
+    want = sum(shard[r + 2 * (s % rot)] for r in range(2) for s in range(steps))
     c = out["counters"]
     assert [c["total"], c["nw_ok"], c["leap_ok"], c["greedy_ok"]] == want.tolist()
-    assert c["total"] == c["expected_total"]
+    assert c["total"] == c["expected_total"] and c["as_expected"] and c["steps_per_batch"] == [2, 1, 1]
+    assert out["config"]["rotation"].startswith("3 resident batches")
     assert out["sequential_mode"]["ms_per_step"] > 0
     # BASELINE configs 4 and 5 ride along in the same N-rank job: C4 strong scaling, C5 bucketed by length (bench.extra_leg)
     for key, wl in (("c4_strong", "C4"), ("c5_bucketed", "C5")):
@@ -50,20 +54,22 @@ def test_self_started_ranks_share_one_stream_with_the_collective(asm, oracle):
         assert leg["ms_per_step"] > 0 and leg["pairs_per_s"] > 0 and leg["allreduce_ms"] is not None
         assert leg["counters_as_expected"] and leg["counters"]["total"] == extra_total * extra_steps
         cfg, _, params = asm.workload(wl)
-        hb = asm.generate_pairs(cfg, 0, extra_total)   # the shards are contiguous slices of this stream
+        hb = asm.generate_pairs(cfg, 0, extra_total * extra_steps)   # step s reads block s of the stream, the shards are contiguous slices of it
         nw, leap, greedy = oracle.nw(hb), oracle.leap(hb, params.k), oracle.greedy(hb, params.k, mode=1)
-        assert leg["counters"]["greedy_ok"] == extra_steps * int((greedy == nw).sum())
+        assert leg["counters"]["greedy_ok"] == int((greedy == nw).sum())
         ok = np.maximum(*hb.lengths()) <= 256   # LEAP beyond 256 bases is undefined in the reference
         if ok.all():
-            assert leg["counters"]["leap_ok"] == extra_steps * int((leap == nw).sum())
+            assert leg["counters"]["leap_ok"] == int((leap == nw).sum())
 
 
 def test_single_rank_through_rccl_and_sequential_leg(asm, oracle):
     n, steps = 30000, 4
-    out = _bench({"ASM_FORCE_DIST": "1"}, "--pairs", str(n), "--steps", str(steps), "--warmup", "1", "--cpu-sample", "30000")
-    want = steps * _expected_counts(asm, oracle, 0, n)
+    out = _bench({"ASM_FORCE_DIST": "1"}, "--pairs", str(n), "--steps", str(steps), "--warmup", "1", "--cpu-sample", "30000", "--rotate", "2")
+    want = 2 * _expected_counts(asm, oracle, 0, n) + 2 * _expected_counts(asm, oracle, n, n)   # two batches, two steps each
     c = out["counters"]
     assert [c["total"], c["nw_ok"], c["leap_ok"], c["greedy_ok"]] == want.tolist()
+    assert c["as_expected"] and c["per_batch_single_pass_rank0"][1] == _expected_counts(asm, oracle, n, n).tolist()
+    assert out["ms_per_step_same_batch"] > 0 and out["pack_GBps"]["rotating"] > 0 and out["pack_GBps"]["same_batch"] > 0
     assert out["bit_exact_pct_vs_oracle"]["greedy"] == 100.0 and out["bit_exact_pct_vs_oracle"]["nw"] == 100.0
     seq = out["sequential_mode"]
     assert seq["greedy_bit_exact_pct_vs_oracle_sequential"] == 100.0

@@ -1,7 +1,6 @@
-"""Every kernel family stays parity-green, not only the default dispatch: the A/B switches of the C-ABI library
-(environment variables read at asm_create) select the alternative kernels — one-pair-per-thread Greedy, lane-refilling
-LEAP, unsorted LEAP, full-height NW, thread-per-pair, workgroup-per-pair and wave-per-pair wide kernels, unbucketed batches — and each is checked against the
-oracle in a fresh process."""
+"""Every kernel family stays parity-green, not only the default dispatch: the switches the C-ABI library keeps (environment
+variables read at asm_create; one fallback per kernel family, the allocator, the stream layout) select the alternative paths,
+and each is checked against the oracle in a fresh process."""
 import os
 import subprocess
 import sys
@@ -52,28 +51,15 @@ print("ok")
 
 
 @pytest.mark.parametrize("env", [
-    {"ASM_PERSIST": "0"},
-    {"ASM_GREEDY_FAST": "0"},
-    {"ASM_GREEDY_PRUNE": "6", "ASM_PERSIST_WIDE": "0"},
-    {"ASM_GREEDY_PRUNE": "17", "ASM_PRUNE_WAVES": "16"},
-    {"ASM_GREEDY_WAVES": "3"},
-    {"ASM_GREEDY_PARK": "1"},
-    {"ASM_GREEDY_PARK": "1", "ASM_GREEDY_WAVES": "3", "ASM_REFILL_GREEDY": "24"},
-    {"ASM_GREEDY_PARK": "0"},
-    {"ASM_GREEDY_WAVES": "1", "ASM_REFILL_GREEDY": "1"},
-    {"ASM_PERSIST_LEAP": "1", "ASM_LEAP_HINT": "0"},
-    {"ASM_LEAP_HINT": "0"},
-    {"ASM_NW_BANDED": "0", "ASM_NW_WFA": "0"},
-    {"ASM_NW_WFA2": "2", "ASM_RING_BYTES": "0"},
-    {"ASM_NW_WFA2": "0", "ASM_RING_BYTES": "1"},
-    {"ASM_WAVE": "0"},
-    {"ASM_LEAP_QUAD": "0"},
-    {"ASM_LEAP_SORT": "0"},
-    {"ASM_LEAP_QUAD": "0", "ASM_LEAP_BAND": "0"},
-    {"ASM_BUCKET": "0"},
-    {"ASM_SIMD_QUAD": "1"},
-    {"ASM_SIMD_QUAD": "100"},
-    {"ASM_REFILL_GREEDY": "1", "ASM_REFILL_LEAP": "64", "ASM_PERSIST_LEAP": "1", "ASM_LEAP_HINT": "0"},
+    {"ASM_GREEDY_FAST": "0"},                      # FP64 lane-refilling Greedy at k <= 3
+    {"ASM_LEAP_HINT": "0"},                        # LEAP in input order
+    {"ASM_LEAP_SORT": "0"},                        # wide-band LEAP: work sort inside workgroups only
+    {"ASM_NW_BANDED": "0", "ASM_NW_WFA": "0"},     # full-height bit-parallel NW, full-matrix affine NW
+    {"ASM_NW_BYLEN": "0"},                         # mixed-length NW without the length sort
+    {"ASM_WAVE": "0"},                             # workgroup-per-pair fallbacks
+    {"ASM_BUCKET": "0"},                           # one width class
+    {"ASM_OVERLAP": "0"},                          # one stream
+    {"ASM_POOL": "0"},                             # plain hipMalloc / hipFree
 ])
 def test_alternative_kernels_match_the_oracle(env):
     e = dict(os.environ)

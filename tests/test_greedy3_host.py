@@ -123,68 +123,3 @@ def test_other_probabilities_with_equal_significances(g3, asm, oracle):
     probs = (0.90, 0.05, 0.10)
     got, _, _ = run(g3, oracle, hb, 3, probs=probs)
     assert np.array_equal(got, oracle.greedy(hb, k=3, mode=1, probs=probs))
-
-
-# ---- the exactly-pruned wide-band pass (csrc/asm_greedy_prune.h) -------------------------------------------------------------
-def run_pruned(g3, orc, hb, k, probs=DEFAULT):
-    views = np.ascontiguousarray(orc.greedy_views(hb, mode=1)).reshape(-1)
-    m, n = hb.lengths()
-    lens = (m.astype(np.uint32) | (n.astype(np.uint32) << 16)).astype(np.uint32)
-    costs, passes, cnt = np.zeros(hb.n, np.int32), np.zeros(hb.n, np.int32), np.zeros(16, np.int64)
-    probs = np.ascontiguousarray(probs, np.float64)
-    g3.pr_host_batch.restype = ctypes.c_int
-    rc = g3.pr_host_batch(ctypes.c_long(hb.n), views.ctypes.data_as(ctypes.c_void_p), lens.ctypes.data_as(ctypes.c_void_p), k,
-                          probs.ctypes.data_as(ctypes.c_void_p), costs.ctypes.data_as(ctypes.c_void_p),
-                          passes.ctypes.data_as(ctypes.c_void_p), cnt.ctypes.data_as(ctypes.c_void_p))
-    assert rc == 0, rc
-    return costs, cnt
-
-
-@pytest.mark.parametrize("wl,n,k", [("C3", 30_000, 30), ("C3", 8_000, 17), ("C2", 15_000, 31), ("C5", 15_000, 24), ("C4", 10_000, 20),
-                                    ("C2", 10_000, 8), ("C2", 10_000, 3)])
-def test_pruned_pass_is_the_reference_pass(g3, asm, oracle, wl, n, k):
-    """The closed form of the reference's per-lane highway cache (cached start = first zero at or after the LARGEST start column
-    the lane has seen; stale num_switches = the first pass that crossed the last zero before it), the per-lane thresholds for
-    reaching_destination and the score bounds by run class: a pass that looks at a handful of lanes commits what the reference's
-    pass over all 2k+1 lanes commits.  Pairs that outrun the pass history are handed back (INT32_MIN), never answered wrongly."""
-    cfg, _, _ = asm.workload(wl)
-    hb = asm.generate_pairs(cfg, 17, n)
-    got, cnt = run_pruned(g3, oracle, hb, k)
-    want = oracle.greedy(hb, k=k, mode=1)
-    settled = got != np.iinfo(np.int32).min
-    assert int((got[settled] != want[settled]).sum()) == 0
-    assert int((~settled).sum()) == int(cnt[6]) <= 2
-    if k >= 17:  # the point of it: a pass looks at a few lanes, not 2k+1
-        assert cnt[1] / cnt[0] < 0.25 * (2 * k + 1)
-
-
-def test_pruned_pass_adversarial(g3, asm, oracle):
-    rng = np.random.default_rng(5)
-    acgt = "ACGT"
-    rnd = lambda L: "".join(acgt[i] for i in rng.integers(0, 4, L))
-    pairs = [("A" * 128, "T" * 128), ("A" * 128, "A" * 128), ("", ""), ("A", ""), ("", "A"), ("AC", "CA"), ("A" * 128, "A" * 100),
-             ("A" * 100, "A" * 128), ("A" * 64 + "T" * 64, "T" * 64 + "A" * 64), ("ACGT" * 32, "CGTA" * 32)]
-    for L in (128, 100, 64, 33, 5):
-        a = rnd(L)
-        pairs += [(a, a), (a, a[7:]), (a[9:], a), (a, "T" * 40 + a[40:]), (a, rnd(L)), (a, a[:L // 2] + rnd(6) + a[L // 2:])]
-    for _ in range(1500):
-        L = int(rng.integers(1, 180))
-        a = list(rnd(L))
-        b = list(a)
-        for _ in range(int(rng.integers(0, 5))):
-            p, w = int(rng.integers(0, L)), int(rng.integers(1, 60))
-            b[p:p + w] = list(acgt[(acgt.index(c) + 1) % 4] for c in b[p:p + w])
-        for _ in range(int(rng.integers(0, 4))):
-            q = int(rng.integers(0, len(b) + 1))
-            if rng.random() < 0.5:
-                b[q:q] = list(rnd(int(rng.integers(1, 12))))
-            else:
-                del b[q:q + int(rng.integers(1, 12))]
-        pairs.append(("".join(a), "".join(b)))
-    hb = asm.HostBatch.from_strings(pairs)
-    for k in (5, 17, 31):
-        got, _ = run_pruned(g3, oracle, hb, k)
-        want = oracle.greedy(hb, k=k, mode=1)
-        settled = got != np.iinfo(np.int32).min
-        bad = np.nonzero((got != want) & settled)[0]
-        assert len(bad) == 0, [(pairs[i], int(got[i]), int(want[i])) for i in bad[:3]]
