@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../include/asm_mi355x.h"
+#include "asm_host.h"
 #include "asm_kernels.h"
 #include "asm_greedy3_kernel.h"
 #include "asm_wide.h"
@@ -718,53 +719,16 @@ int asm_pipeline_join_async(asm_handle* h) {
 
 /* ---------------------------------------------------------------------------------------------------- */
 static int check_gen(const asm_gen_config* cfg) {
-    if (!cfg) return fail(nullptr, ASM_EINVAL, "generator: cfg is NULL");
-    if (cfg->len_lo < 1 || cfg->len_hi < cfg->len_lo || cfg->len_hi > ASM_MAX_LENGTH)
-        return fail(nullptr, ASM_EINVAL, "generator: need 1 <= len_lo <= len_hi <= ASM_MAX_LENGTH");
-    if (cfg->kind == ASM_GEN_EXACT_ERRORS || cfg->kind == ASM_GEN_UP_TO_ERRORS) {
-        /* benchmark_dataset.h:192-204 */
-        if (!(cfg->err >= 0.f && cfg->err <= 0.7f)) return fail(nullptr, ASM_EINVAL, "generator: err must be in [0, 0.7]");
-        if (!(cfg->mismatch_rate >= 0.f && cfg->mismatch_rate <= 1.f))
-            return fail(nullptr, ASM_EINVAL, "generator: mismatch_rate must be in [0, 1]");
-    } else if (cfg->kind == ASM_GEN_PER_BASE) {
-        if (!(cfg->p_sub >= 0.f && cfg->p_ins >= 0.f && cfg->p_del >= 0.f && cfg->p_sub + cfg->p_del <= 1.f &&
-              cfg->p_ins <= 1.f))
-            return fail(nullptr, ASM_EINVAL, "generator: per-base rates out of range");
-    } else {
-        return fail(nullptr, ASM_EINVAL, "generator: unknown kind");
-    }
-    return ASM_OK;
+    std::string err;
+    const int rc = asm_host::check_gen(cfg, err);
+    return rc ? fail(nullptr, rc, err) : ASM_OK;
 }
 
 int asm_generate_pairs(const asm_gen_config* cfg, int64_t first, int64_t n, uint32_t* read_off, uint32_t* ref_off,
                        char* reads, size_t reads_cap, char* refs, size_t refs_cap) {
-    int rc = check_gen(cfg);
-    if (rc) return rc;
-    if (n < 0 || first < 0 || !read_off || !ref_off) return fail(nullptr, ASM_EINVAL, "asm_generate_pairs: bad arguments");
-    uint64_t ra = 0, rb = 0;
-    for (int64_t i = 0; i < n; i++) {
-        int m, nn;
-        asm_gen_lengths(cfg, (uint64_t)(first + i), &m, &nn);
-        read_off[i] = (uint32_t)ra;
-        ref_off[i] = (uint32_t)rb;
-        ra += (uint64_t)m;
-        rb += (uint64_t)nn;
-        if (ra > 0xffffffffull || rb > 0xffffffffull)
-            return fail(nullptr, ASM_EUNSUPPORTED, "asm_generate_pairs: batch exceeds 4 GiB of text; split it");
-    }
-    read_off[n] = (uint32_t)ra;
-    ref_off[n] = (uint32_t)rb;
-    if (!reads || !refs) return ASM_OK; /* sizing pass */
-    if (reads_cap < ra || refs_cap < rb) return fail(nullptr, ASM_EINVAL, "asm_generate_pairs: output buffers too small");
-#pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < n; i++) {
-        char rd[ASM_MAX_LENGTH + 8], tx[ASM_GEN_MAX_TEXT];
-        int m, nn;
-        asm_gen_pair(cfg, (uint64_t)(first + i), rd, tx, &m, &nn);
-        memcpy(reads + read_off[i], rd, (size_t)m);
-        memcpy(refs + ref_off[i], tx, (size_t)nn);
-    }
-    return ASM_OK;
+    std::string err;
+    const int rc = asm_host::generate_pairs(cfg, first, n, read_off, ref_off, reads, reads_cap, refs, refs_cap, err);
+    return rc ? fail(nullptr, rc, err) : ASM_OK;
 }
 
 /* ---------------------------------------------------------------------------------------------------- */
@@ -1207,16 +1171,9 @@ int asm_batch_tail_summary(asm_handle* h, const asm_batch* b, uint8_t* summary) 
 }
 
 int asm_tail_state_advance(uint8_t* state, const uint8_t* summary, int64_t n_pairs) {
-    if (!state || !summary || n_pairs < 0) return fail(nullptr, ASM_EINVAL, "asm_tail_state_advance: bad argument");
-    uint8_t next[256];
-    for (int side = 0; side < 2; side++)
-        for (int s = 0; s < 128; s++) {
-            const uint8_t w = summary[side * 128 + s];
-            if (w != TAIL_NONE && w > 3) return fail(nullptr, ASM_EINVAL, "asm_tail_state_advance: summary entries are 0..3 or 0xFF");
-            next[side * 128 + tail_slot_after(s, (long long)n_pairs)] = w != TAIL_NONE ? w : state[side * 128 + s];
-        }
-    memcpy(state, next, 256);
-    return ASM_OK;
+    std::string err;
+    const int rc = asm_host::tail_state_advance(state, summary, n_pairs, err);
+    return rc ? fail(nullptr, rc, err) : ASM_OK;
 }
 
 int asm_batch_resolve_tails(asm_handle* h, asm_batch* b, const uint8_t* state) {
@@ -1518,17 +1475,7 @@ int asm_greedy_cigar_batch_async(asm_handle* h, const asm_batch* b, const asm_pa
 }
 
 int asm_cigar_format(const uint16_t* ops, int nops, int cap, char* out, size_t out_cap) {
-    if (!ops || !out || out_cap == 0) return ASM_EINVAL;
-    size_t len = 0;
-    out[0] = 0;
-    const int cnt = nops < cap ? nops : cap;
-    for (int i = 0; i < cnt; i++) {
-        const char op = "MID=X???"[ops[i] & 7];
-        const int w = snprintf(out + len, out_cap - len, "%d%c", (int)(ops[i] >> 3), op);
-        if (w < 0 || len + (size_t)w >= out_cap) return ASM_EINVAL;
-        len += (size_t)w;
-    }
-    return nops > cap ? ASM_EUNSUPPORTED : ASM_OK; /* truncated row */
+    return asm_host::cigar_format(ops, nops, cap, out, out_cap);
 }
 
 int asm_coverage(asm_handle* h, const asm_batch* b, const asm_params* p, const uint16_t* d_greedy_ops, int greedy_cap,
@@ -1893,6 +1840,12 @@ int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, in
             b->bk[q].lens = b->d_lens + b->pb.start[q];
         }
         HIPCHK(h, hipStreamWaitEvent(h->pack_stream, b->ev_consumed[nxt], 0));
+        /* Overlapped calls on DIFFERENT batches (a caller rotating over several resident batches): the plane set of this batch
+         * was consumed long ago, so nothing above holds the pack back, and the pack chain would run as many calls ahead as the
+         * host has enqueued — thousands of short pack workgroups dispatched beside every persistent Greedy kernel (0.258 ms per
+         * step against 0.218 on one batch).  Pace it as one batch paces itself: the pack of call c behind the counters of call
+         * c - 2 (the event that also frees that call's output arrays). */
+        if (repack == 3 && h->calls3 >= 2) HIPCHK(h, hipStreamWaitEvent(h->pack_stream, h->ev_out[h->calls3 & 1u], 0));
         if (!h->pipe_prev) { /* first of a run of pipelined calls: behind whatever the caller's stream holds so far */
             HIPCHK(h, hipEventRecord(h->ev_fork, main_stream));
             HIPCHK(h, hipStreamWaitEvent(h->pack_stream, h->ev_fork, 0));
@@ -2043,161 +1996,8 @@ int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, in
  *                    chunks before left behind], NW / LEAP / Greedy, counters, penalties back into pinned staging
  *   caller's thread  hands results of chunk c-2 to the caller's arrays while chunk c-1 computes and chunk c is copied */
 namespace {
-
-struct SeqSlot { /* one pinned host buffer */
-    char* buf = nullptr;
-    size_t cap = 0;
-    size_t bytes = 0;     /* raw bytes to ship: whole pairs only */
-    int64_t pairs = 0;
-    bool last = false;
-    bool ready = false;   /* filled by the reader, not yet shipped */
-    bool in_flight = false; /* an H2D copy out of it has been enqueued; ev_shipped tells when it is over */
-    hipEvent_t ev_shipped = nullptr;
-};
-
-/* newlines in [p, p+len): count and the positions (relative to p) of the last two */
-struct NlScan {
-    int64_t count = 0;
-    int64_t last = -1, prev = -1;
-};
-static NlScan scan_newlines(const char* p, size_t len, int threads) {
-    if (threads < 1) threads = 1;
-    std::vector<NlScan> part((size_t)threads);
-    std::vector<std::thread> pool;
-    const size_t step = (len + (size_t)threads - 1) / (size_t)threads;
-    auto work = [&](int t) {
-        const size_t a = (size_t)t * step, b = a + step < len ? a + step : len;
-        NlScan r;
-        const char* q = p + a;
-        const char* end = p + (a < b ? b : a);
-        while (q < end) {
-            const char* hit = (const char*)memchr(q, '\n', (size_t)(end - q));
-            if (!hit) break;
-            r.count++, r.prev = r.last, r.last = (int64_t)(hit - p);
-            q = hit + 1;
-        }
-        part[(size_t)t] = r;
-    };
-    for (int t = 1; t < threads; t++) pool.emplace_back(work, t);
-    work(0);
-    for (auto& th : pool) th.join();
-    NlScan tot;
-    for (const NlScan& r : part) {
-        if (!r.count) continue;
-        tot.count += r.count;
-        if (r.count >= 2) tot.prev = r.prev;
-        else tot.prev = tot.last; /* the segment's only newline: the one before it is the running last */
-        tot.last = r.last;
-    }
-    return tot;
-}
-
-/* Worker threads that live as long as one asm_stream_seq_file call: a chunk is read AND scanned for newlines by the same
- * workers in one go (each its own slice: pread into the pinned buffer, then memchr over the bytes it has just written).
- * Round 2 started 2 x 8 threads per chunk — half a millisecond of every 64 MB chunk — and passed over the data twice. */
-class StreamWorkers {
-    std::vector<std::thread> threads_;
-    std::mutex mu_;
-    std::condition_variable cv_work_, cv_done_;
-    std::function<void(int)> job_;
-    int generation_ = 0, pending_ = 0;
-    bool quit_ = false;
-
-public:
-    explicit StreamWorkers(int n) {
-        for (int t = 0; t < n; t++)
-            threads_.emplace_back([this, t]() {
-                int seen = 0;
-                for (;;) {
-                    std::function<void(int)> job;
-                    {
-                        std::unique_lock<std::mutex> lk(mu_);
-                        cv_work_.wait(lk, [&] { return quit_ || generation_ != seen; });
-                        if (quit_) return;
-                        seen = generation_;
-                        job = job_;
-                    }
-                    job(t);
-                    {
-                        std::lock_guard<std::mutex> lk(mu_);
-                        if (--pending_ == 0) cv_done_.notify_all();
-                    }
-                }
-            });
-    }
-    int size() const { return (int)threads_.size(); }
-    void run(const std::function<void(int)>& job) { /* job(t) on every worker t; returns when all are done */
-        std::unique_lock<std::mutex> lk(mu_);
-        job_ = job;
-        pending_ = (int)threads_.size();
-        generation_++;
-        cv_work_.notify_all();
-        cv_done_.wait(lk, [&] { return pending_ == 0; });
-    }
-    ~StreamWorkers() {
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            quit_ = true;
-        }
-        cv_work_.notify_all();
-        for (auto& th : threads_) th.join();
-    }
-};
-
-/* buf[0, head) is already there (the carry of the chunk before); reads `len` file bytes behind it and returns the newline
- * summary of buf[0, head + len) */
-static NlScan read_and_scan(StreamWorkers& pool, int fd, char* buf, size_t head, size_t len, off_t off, std::atomic<bool>& failed) {
-    const int threads = pool.size();
-    std::vector<NlScan> part((size_t)threads + 1);
-    const size_t step = ((len + (size_t)threads - 1) / (size_t)threads + 4095) & ~(size_t)4095;
-    auto scan = [&](size_t a, size_t b) { /* newlines of buf[a, b), positions relative to buf */
-        NlScan r;
-        const char* q = buf + a;
-        const char* end = buf + (a < b ? b : a);
-        while (q < end) {
-            const char* hit = (const char*)memchr(q, '\n', (size_t)(end - q));
-            if (!hit) break;
-            r.count++, r.prev = r.last, r.last = (int64_t)(hit - buf);
-            q = hit + 1;
-        }
-        return r;
-    };
-    part[0] = scan(0, head);
-    pool.run([&](int t) {
-        /* read and scan in blocks of 1 MB: the scan then finds the bytes the copy has just written still in the core's cache
-         * (scanning an 8 MB slice after reading all of it fetched every byte from DRAM a second time) */
-        const size_t a0 = (size_t)t * step, b = a0 + step < len ? a0 + step : len;
-        NlScan mine;
-        for (size_t a = a0; a < b;) {
-            const size_t blk_end = a + ((size_t)1 << 20) < b ? a + ((size_t)1 << 20) : b;
-            const size_t blk_a = a;
-            while (a < blk_end) {
-                const ssize_t got = pread(fd, buf + head + a, blk_end - a, off + (off_t)a);
-                if (got <= 0) {
-                    failed = true;
-                    return;
-                }
-                a += (size_t)got;
-            }
-            const NlScan r = scan(head + blk_a, head + blk_end);
-            if (r.count) {
-                mine.count += r.count;
-                mine.prev = r.count >= 2 ? r.prev : mine.last;
-                mine.last = r.last;
-            }
-        }
-        part[(size_t)t + 1] = mine;
-    });
-    NlScan tot;
-    for (const NlScan& r : part) {
-        if (!r.count) continue;
-        tot.count += r.count;
-        if (r.count >= 2) tot.prev = r.prev;
-        else tot.prev = tot.last; /* the segment's only newline: the one before it is the running last */
-        tot.last = r.last;
-    }
-    return tot;
-}
+using asm_host::NlScan;
+using asm_host::scan_newlines;
 
 /* A batch out of raw text already in HBM (n pairs = 2n lines, every line ending in '\n'). */
 static int batch_from_device_text(asm_handle* h, const char* d_raw, size_t nbytes, int64_t n, int greedy_mode, asm_batch** out) {
@@ -2337,7 +2137,13 @@ int asm_stream_seq_file(asm_handle* h, const char* path, const asm_params* p, in
     if (const char* env = getenv("ASM_READER_THREADS")) reader_threads = atoi(env) > 0 ? atoi(env) : reader_threads;
     const auto t_begin = std::chrono::steady_clock::now();
 
-    SeqSlot slot[3];
+    hipEvent_t ev_shipped[3] = {nullptr, nullptr, nullptr}; /* the H2D copy out of host slot q is over */
+    /* the reader side lives in asm_host.h (no HIP there: the same code runs under ThreadSanitizer in host/asm_host_check.cpp);
+     * the one thing it needs from the device is "has the copy out of this slot finished" */
+    asm_host::SeqReader rd(fd, file_bytes, chunk, reader_threads, max_pairs, [&](int q) {
+        (void)hipSetDevice(h->device);
+        (void)hipEventSynchronize(ev_shipped[q]);
+    });
     char* d_raw[2] = {nullptr, nullptr};
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
@@ -2347,23 +2153,11 @@ int asm_stream_seq_file(asm_handle* h, const char* path, const asm_params* p, in
     unsigned long long* d_cnt = nullptr;
     int64_t pen_cap = 0;
     int rc = ASM_OK;
-    std::mutex mu;
-    std::condition_variable cv;
-    std::atomic<bool> failed(false), stop(false);
-    double read_seconds = 0;
-    std::thread reader;
-
     auto cleanup = [&]() {
-        {   /* under the mutex: the reader evaluates its wait predicate under it, and a store between its test and its block
-               would otherwise be a lost wake-up */
-            std::lock_guard<std::mutex> lk(mu);
-            stop = true;
-        }
-        cv.notify_all();
-        if (reader.joinable()) reader.join();
+        rd.stop();
         (void)hipDeviceSynchronize();
-        for (auto& s : slot)
-            if (s.ev_shipped) (void)hipEventDestroy(s.ev_shipped);
+        for (hipEvent_t ev : ev_shipped)
+            if (ev) (void)hipEventDestroy(ev);
         for (int q = 0; q < 2; q++) {
             pool_free(h, d_raw[q]);
             if (ev_h2d[q]) (void)hipEventDestroy(ev_h2d[q]);
@@ -2388,9 +2182,9 @@ int asm_stream_seq_file(asm_handle* h, const char* path, const asm_params* p, in
         if (!rc) h->pin_raw_cap = slot_cap;
     }
     for (int q = 0; q < 3; q++) {
-        slot[q].buf = h->pin_raw[q];
-        slot[q].cap = slot_cap;
-        STREAM_TRY(hipEventCreateWithFlags(&slot[q].ev_shipped, hipEventDisableTiming));
+        rd.slot[q].buf = h->pin_raw[q];
+        rd.slot[q].cap = slot_cap;
+        STREAM_TRY(hipEventCreateWithFlags(&ev_shipped[q], hipEventDisableTiming));
     }
     for (int qq = 0; qq < 2; qq++)
         for (int a = 0; a < 3; a++) h_pen[qq][a] = h->pin_pen[qq][a];
@@ -2417,70 +2211,7 @@ int asm_stream_seq_file(asm_handle* h, const char* path, const asm_params* p, in
         return rc;
     }
 
-    /* ---- reader: fills slots in rotation ---- */
-    reader = std::thread([&]() {
-        (void)hipSetDevice(h->device);
-        StreamWorkers workers(reader_threads);
-        std::vector<char> carry;
-        size_t file_off = 0;
-        int64_t pairs_left = max_pairs > 0 ? max_pairs : INT64_MAX;
-        bool eof = false;
-        for (int c = 0; !eof && !stop; c++) {
-            SeqSlot& s = slot[c % 3];
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return stop || !s.ready; });
-                if (stop) return;
-            }
-            if (s.in_flight) { /* the copy out of this buffer (three chunks ago) must be over before it is overwritten */
-                (void)hipEventSynchronize(s.ev_shipped);
-                s.in_flight = false;
-            }
-            const auto t0 = std::chrono::steady_clock::now();
-            size_t have = carry.size();
-            if (have) memcpy(s.buf, carry.data(), have);
-            carry.clear();
-            size_t want = chunk;
-            if (file_off + want > file_bytes) want = file_bytes - file_off;
-            if (have + want > s.cap - 8) want = s.cap - 8 - have;
-            NlScan sc = read_and_scan(workers, fd, s.buf, have, want, (off_t)file_off, failed);
-            file_off += want;
-            have += want;
-            eof = file_off >= file_bytes;
-            if (eof && have && s.buf[have - 1] != '\n') { /* a last line without its newline */
-                s.buf[have++] = '\n';
-                sc.prev = sc.last, sc.last = (int64_t)have - 1, sc.count++;
-            }
-            if (eof && (sc.count & 1)) { /* a read line without its reference line: an empty reference */
-                s.buf[have++] = '\n';
-                sc.prev = sc.last, sc.last = (int64_t)have - 1, sc.count++;
-            }
-            int64_t lines = sc.count & ~(int64_t)1;
-            size_t boundary = lines == 0 ? 0 : (size_t)((lines == sc.count ? sc.last : sc.prev) + 1);
-            if (lines / 2 > pairs_left) { /* max_pairs cuts inside this chunk: find the boundary of the pairs_left-th pair */
-                const int64_t need = 2 * pairs_left;
-                const char* q = s.buf;
-                for (int64_t l = 0; l < need; l++) q = (const char*)memchr(q, '\n', (size_t)(s.buf + have - q)) + 1;
-                boundary = (size_t)(q - s.buf), lines = need;
-                eof = true;
-            }
-            if (!eof) {
-                /* (the two bytes the reader may append above stay inside the slot: reads stop at cap - 8 and every slot was
-                 * allocated with cap + 64) */
-                if (boundary == 0 && have >= s.cap - 8) failed = true; /* one pair longer than a whole chunk */
-                carry.assign(s.buf + boundary, s.buf + have);
-            }
-            pairs_left -= lines / 2;
-            if (pairs_left <= 0) eof = true;
-            read_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                s.bytes = boundary, s.pairs = lines / 2, s.last = eof, s.ready = true;
-            }
-            cv.notify_all();
-            if (failed) return;
-        }
-    });
+    rd.start(); /* the reader thread: fills the three slots in rotation (asm_host::SeqReader) */
 
     /* ---- caller's thread: ship, compute, harvest ---- */
     uint8_t tail_state[256];
@@ -2585,35 +2316,29 @@ int asm_stream_seq_file(asm_handle* h, const char* path, const asm_params* p, in
         done_pairs += n, bytes_total += shipped, chunks++;
     };
     for (int c = 0; !last && !rc; c++) {
-        SeqSlot& s = slot[c % 3];
-        {
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return s.ready || failed.load(); });
-        }
-        if (failed) {
+        asm_host::SeqSlot* sp = rd.wait_ready(c);
+        if (!sp) {
             rc = fail(h, ASM_EINVAL, "asm_stream_seq_file: read failed (or one pair is longer than a chunk)");
             break;
         }
+        asm_host::SeqSlot& s = *sp;
         const int q = c & 1;
         /* SHIP chunk c.  d_raw[q] held chunk c-2, which was processed (and its text gathered into the batch's own arrays, with
          * this thread waiting for that) in the iteration before this one. */
         last = s.last;
+        bool shipping = false;
         if (s.pairs > 0) {
             STREAM_TRY(hipMemcpyAsync(d_raw[q], s.buf, s.bytes, hipMemcpyHostToDevice, copy_stream));
-            STREAM_TRY(hipEventRecord(s.ev_shipped, copy_stream));
-            s.in_flight = true;
+            STREAM_TRY(hipEventRecord(ev_shipped[c % 3], copy_stream));
+            shipping = !rc;
             STREAM_TRY(hipEventRecord(ev_h2d[q], copy_stream));
         }
         pend_pairs[q] = s.pairs, pend_bytes[q] = s.bytes, pend_valid[q] = true;
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            s.ready = false; /* the reader may refill it once ev_shipped has fired */
-        }
-        cv.notify_all();
+        rd.consumed(c, shipping); /* the reader may refill the slot once ev_shipped has fired */
         /* PROCESS chunk c-1 while chunk c is on its way */
         process(q ^ 1);
     }
-    if (!rc && !failed) process(0), process(1); /* the last chunk shipped (only one of the two is pending) */
+    if (!rc && !rd.failed()) process(0), process(1); /* the last chunk shipped (only one of the two is pending) */
     harvest(0), harvest(1);
     if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(h, ASM_ENODEVICE, "asm_stream_seq_file: stream synchronize failed");
     if (!rc && hipMemcpy(stats->counters, d_cnt, 32, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(h, ASM_ENODEVICE, "asm_stream_seq_file: counters copy failed");
@@ -2621,7 +2346,7 @@ int asm_stream_seq_file(asm_handle* h, const char* path, const asm_params* p, in
     cleanup();
     stats->pairs = done_pairs, stats->chunks = chunks, stats->bytes = (int64_t)bytes_total, stats->max_length = maxlen;
     stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
-    stats->seconds_read = read_seconds;
+    stats->seconds_read = rd.read_seconds();
     return rc;
 }
 

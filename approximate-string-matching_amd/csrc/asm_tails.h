@@ -22,10 +22,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "asm_host.h" /* TAIL_NONE, tail_slot_after: the host side of the chain */
+
 #define TAIL_CHUNK 640  /* pairs per chunk: a multiple of 10 (the order of SRC); 10^6 pairs = 1563 workgroups, one round of the chip */
 #define TAIL_SUB 256    /* pairs whose tail planes are accumulated in LDS at a time */
 #define TAIL_BATCH 16   /* pairs whose plane words are fetched ahead (the walk is a chain of dependent round trips to HBM) */
-#define TAIL_NONE 0xFFu
 
 // SRC^-1: SRC[q] = 8*(q & 15) + P[q >> 4] and P is an involution, so q = (P[y & 7] << 4) | (y >> 3).
 __device__ __forceinline__ int tail_src_inv(int y) {
@@ -151,16 +152,6 @@ __global__ __launch_bounds__(256 * TAIL_CARRY_SEGS) void tails_carry_kernel(cons
             if (s_seg[q][tr] != TAIL_NONE) all = s_seg[q][tr];
         summary[tr] = (uint8_t)all;
     }
-}
-
-// Host: where the trajectory that starts in `slot` sits after n pairs (SRC has order 10).
-static inline int tail_slot_after(int slot, long long n) {
-    for (int i = 0, r = (int)(n % 10); i < r; i++) {
-        const int v = slot & 7, low2 = v & 3;
-        const int pv = (low2 == 1 || low2 == 2) ? (v ^ 3) : v;
-        slot = (pv << 4) | (slot >> 3);
-    }
-    return slot;
 }
 
 __global__ __launch_bounds__(256) void tails_emit_kernel(const uint4* __restrict__ planes,

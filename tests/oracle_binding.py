@@ -7,7 +7,8 @@ import subprocess
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ORACLE_SO = os.path.join(ROOT, "oracle", "libasm_oracle.so")
+# ASM_ORACLE_LIB: another build of the same checker (tests/test_sanitizers.py points it at the ASan + UBSan build)
+ORACLE_SO = os.environ.get("ASM_ORACLE_LIB") or os.path.join(ROOT, "oracle", "libasm_oracle.so")
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libasm_ref.so")
 REF_SIMD_SO = os.path.join(ROOT, "oracle", "_ref", "libasm_ref_simd.so")
 REF_DATASET = os.path.join(ROOT, "oracle", "_ref", "ref_dataset")  # the reference's own Dataset generator with a settable seed

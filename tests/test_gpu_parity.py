@@ -972,23 +972,62 @@ def test_fast_greedy_kernel_slow_path_and_corners(asm, engine, oracle, k):
         batch.free()
 
 
-def test_the_reference_mains_run_on_the_library(asm):
-    """GASMA/main.cpp and GASMA/benchmark/benchmark.cpp, compiled unmodified against host/compat (oracle/Makefile `shim`, in the
-    build container) and run HERE on the GPU: the one-pair demo prints what the reference's own build of the same file printed
-    (tests/golden/gasma_main_stdout.txt: the seven lane rows, `22M1D50M1D28M`, `cost: 6`, the LCM string), and the benchmark
-    main — whose data path does not exist outside the author's machine — goes through its whole call sequence."""
+def _results_block(stdout):
+    """[total, nw %, leap %, greedy %, coverage %] out of the harness's print() block (benchmark_utils.h:391-401)."""
+    import re
+
+    total = int(re.search(r"Total number of alignments: (\d+)", stdout).group(1))
+    acc = stdout[stdout.index("[Accuracy]"):]
+    pct = [float(v) for v in re.findall(r"\| (\d+\.\d+) %", acc)]
+    return [total] + pct[:4]
+
+
+def test_the_reference_mains_run_on_the_library(asm, oracle, tmp_path):
+    """The drop-in claim on the reference's own callers, run HERE on the GPU (executables built by oracle/Makefile `shim` in the
+    build container, reference sources compiled in place and unmodified):
+      * gasma_main_on_shim      GASMA/main.cpp against host/compat: prints what the reference's own build of the same file printed
+                                (tests/golden/gasma_main_stdout.txt: the seven lane rows, `22M1D50M1D28M`, `cost: 6`, the LCM string);
+      * benchmark_main_on_shim  GASMA/benchmark/benchmark.cpp against host/compat's batched `benchmark` class;
+      * ref_harness_on_shim     GASMA/benchmark/benchmark.cpp WITH THE REFERENCE'S OWN benchmark_utils.h (class benchmark, its
+                                parasail / LV / hurdle_matrix calls and its coverage check) over host/compat/parasail/parasail.h and
+                                the per-pair LV / hurdle_matrix objects.
+    benchmark.cpp reads a hard-coded /home/zhenhao/... file: without it both harness executables go through their whole call
+    sequence over zero pairs; with a 2000-pair SRR-shaped (C4) file answered under that name (oracle/_ref/libpath_redirect.so:
+    the path is redirected at the C-library boundary, the programs are not touched) both print the [Accuracy] / [Coverage] block
+    with exactly the oracle's counters — Greedy in the reference's as-run, order-dependent mode."""
     import subprocess
 
     ref_dir = os.path.join(ROOT, "oracle", "_ref")
     demo, bench_main = os.path.join(ref_dir, "gasma_main_on_shim"), os.path.join(ref_dir, "benchmark_main_on_shim")
-    if not (os.path.exists(demo) and os.path.exists(bench_main)):
+    ref_harness, redirect = os.path.join(ref_dir, "ref_harness_on_shim"), os.path.join(ref_dir, "libpath_redirect.so")
+    if not all(os.path.exists(f) for f in (demo, bench_main, ref_harness, redirect)):
         pytest.skip("oracle/_ref/*_on_shim are built only where /root/reference exists")
     out = subprocess.run([demo], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr[-2000:]
     want = open(os.path.join(ROOT, "tests", "golden", "gasma_main_stdout.txt")).read()
     assert out.stdout == want
-    out = subprocess.run([bench_main], capture_output=True, text=True, timeout=120)
-    assert out.returncode == 0, out.stderr[-2000:]
-    assert "Unable to open data file: /home/zhenhao/dna-align-dataset/SRR611076.data" in out.stdout
-    assert "===================== Benchmark Results =====================" in out.stdout
-    assert "Total number of alignments: 0" in out.stdout
+    data_path = "/home/zhenhao/dna-align-dataset/SRR611076.data"   # benchmark.cpp:28
+    for exe in (bench_main, ref_harness):
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert "Unable to open data file: " + data_path in out.stdout
+        assert "===================== Benchmark Results =====================" in out.stdout
+        assert "Total number of alignments: 0" in out.stdout
+    # ... and on data
+    cfg, _, params = asm.workload("C4")
+    n = 2000
+    hb = asm.generate_pairs(cfg, 4242, n)
+    path = str(tmp_path / "SRR611076.data")
+    hb.write_seq_file(path)
+    nw, ncig = oracle.nw_cigar(hb)
+    leap = oracle.leap(hb, k=3)
+    greedy, gcig = oracle.greedy(hb, k=3, mode=0, cigars=True)   # mode 0: the stale-buffer chain of one object over the whole file
+    cov = oracle.coverage(hb, gcig, 1, ncig, 3)
+    want = [n, 100.0, round(100.0 * float((leap == nw).mean()), 3), round(100.0 * float((greedy == nw).mean()), 3),
+            round(100.0 * float(cov.mean()), 3)]
+    env = dict(os.environ, LD_PRELOAD=redirect, ASM_REDIRECT_FROM=data_path, ASM_REDIRECT_TO=path)
+    for exe in (bench_main, ref_harness):
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, (exe, out.stderr[-2000:])
+        assert "Processed data file: " + data_path in out.stdout
+        assert _results_block(out.stdout) == want, (exe, out.stdout[-1500:], want)

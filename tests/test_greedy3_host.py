@@ -12,7 +12,7 @@ from tests import oracle_binding, util
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "approximate-string-matching_amd")
-SO = os.path.join(PKG, "libg3_hostcheck.so")
+SO = os.environ.get("ASM_G3_HOSTCHECK_LIB") or os.path.join(PKG, "libg3_hostcheck.so")  # override: the sanitizer build
 DEFAULT = np.array(oracle_binding.DEFAULT_PROBS, np.float64)
 
 
