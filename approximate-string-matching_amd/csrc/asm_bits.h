@@ -89,6 +89,30 @@ ASM_DEV void v_highway_from(V128 v, int start, int& fz, int& nx) {
     nx = a1 == 128 ? 128 : a1 - a0;
 }
 
+// The same two scans for a caller that keeps, per vector, the complement and the two "first one in the upper word" fall-backs
+// (fb = 64 + ctz(hi), or 128 for an empty upper word) in registers: v_ffbl_b32 gives 0xFFFFFFFF for an empty word, and with
+// saturating adds an empty shifted word turns into a candidate that loses every min() — 10 instructions per scan instead of 14,
+// no compare-and-select chain (the wave-per-pair Greedy kernel runs both scans in every step, whatever its lanes need).
+ASM_DEV unsigned v_ffbl_raw(unsigned x) {
+    unsigned r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+ASM_DEV unsigned v_upper_fallback(V128 v) { return v.hi ? 64u + (unsigned)__builtin_ctzll(v.hi) : 128u; }
+ASM_DEV int v_next_one_from_fb(V128 v, unsigned fb_hi, int from) { /* = v_next_one_from(v, from) for from >= 0 */
+    const bool low = from < 64;
+    const u64 y = (low ? v.lo : v.hi) >> (from & 63);
+    const unsigned c = min(v_ffbl_raw((unsigned)y), __builtin_elementwise_add_sat(v_ffbl_raw((unsigned)(y >> 32)), 32u));
+    const unsigned cand = __builtin_elementwise_add_sat((unsigned)from, c);
+    return (int)min(cand, low ? fb_hi : 128u);
+}
+ASM_DEV void v_highway_from_fb(V128 v, V128 nv /* ~v */, unsigned fb_v, unsigned fb_nv, int start, int& fz, int& nx) {
+    const int a0 = v_next_one_from_fb(nv, fb_nv, start);
+    const int a1 = v_next_one_from_fb(v, fb_v, a0);
+    fz = (unsigned)start >= 128u ? 0 : a0 - start;
+    nx = a1 == 128 ? 128 : a1 - a0;
+}
+
 ASM_DEV int v_popcount(V128 v) { return __popcll(v.lo) + __popcll(v.hi); }
 
 // ones at index >= s (any s >= 0; 0 from 128 on).  A popcount does not care where the surviving bits end up, so instead of
@@ -123,11 +147,13 @@ ASM_DEV int lane_penalty(int a, int b, int o, int e) {
     return d == 0 ? 0 : o + e * (d - 1);
 }
 
-// utils.h:587-593
+// utils.h:587-593: same sign (l1 * l2 >= 0) -> max(|l1| - |l2|, 0), opposite signs -> |l1|.  The sign test is an xor instead of
+// the reference's product (a quarter-rate v_mul_lo): the two differ only when one lane is 0, and there both branches give the
+// same value (l1 == 0: both 0; l2 == 0: both |l1|).
 ASM_DEV int fwd_col(int l1, int l2) {
     int a1 = l1 < 0 ? -l1 : l1, a2 = l2 < 0 ? -l2 : l2;
     int same = a1 > a2 ? a1 - a2 : 0;
-    return (l1 * l2 >= 0) ? same : a1;
+    return ((l1 ^ l2) < 0) ? a1 : same;
 }
 
 // hurdle_matrix.h:58-68

@@ -498,9 +498,22 @@ static inline size_t nw_oct_lds(int w32, int K, int gm, int gi, size_t en_bytes)
 }
 
 // --------------------------------------------------------------------------------------------------------
-// Greedy, wave per pair.  Same step structure as greedy_kernel<K> (hurdle_matrix.h:285-434,568-597); lane t of the
+// Greedy, wave per pair.  Same step structure as greedy_persist_kernel<K> (hurdle_matrix.h:285-434,568-597); lane t of the
 // wave is band lane t - k.
+// Round 4 (C3: 13.5 -> see DESIGN.md): the kernel is VALU-issue bound and a wave executes every instruction whether one band
+// lane needs it or sixty-one, so only the instruction COUNT matters.  (i) The lane vectors are built on four 32-bit words: a
+// band lane is at most 31 positions off the main diagonal, so the 128-bit shift of _construct_hurdles is four v_alignbit_b32,
+// and flip_short_hurdles' two shifts by one are eight more; (ii) the final hop reads the destination lane's vector out of the
+// lane that holds it (v_readlane) and counts its hurdles in scalar registers instead of rebuilding the vector with one active
+// thread; (iii) _choose_best_highway's per-lane tail count runs only when some lane passes the tests that need no count
+// (switch + hurdles within the best lane's cost, start not behind the best lane's); (iv) fwd_col without the multiply.
 // --------------------------------------------------------------------------------------------------------
+ASM_DEV uint4 w_toward0_small(uint4 v, uint32_t s /* 0..31 */) { /* utils.h:143-153 on four words, shift below 32 */
+    return make_uint4(__builtin_amdgcn_alignbit(v.y, v.x, s), __builtin_amdgcn_alignbit(v.z, v.y, s),
+                      __builtin_amdgcn_alignbit(v.w, v.z, s), v.w >> s);
+}
+ASM_DEV V128 v_from_words(uint4 q) { return v_from_uint4(q); }
+
 template <bool UNIT> /* UNIT: x = o = e = 1 at compile time */
 __global__ __launch_bounds__(ASM_BLOCK) void greedy_wave_kernel(const uint4* __restrict__ planes,
                                                                 const uint32_t* __restrict__ lens, long n, int w4,
@@ -512,24 +525,38 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_wave_kernel(const uint4* __r
     const int nl = 2 * k + 1;
     const bool active = t < nl;
     const int lane = t - k;
+    const bool neg = lane < 0;
+    const uint32_t sh = (uint32_t)(active ? (neg ? -lane : lane) : 0); /* <= 31 */
     const int x = UNIT ? 1 : args.x, o = UNIT ? 1 : args.o, e = UNIT ? 1 : args.e;
     const bool semi = UNIT ? false : args.semi != 0;
-    const long n_work = list ? (long)*list_count : n; /* a list of pair slots (what the pruned kernel handed back), or all of them */
+    const long n_work = list ? (long)*list_count : n; /* a list of pair slots, or all of them */
     PairQueue pq;
     for (long iq = pq.first(queue, n_work); iq < n_work; iq = pq.next(queue, iq, n_work)) {
         const long i = list ? (long)list[iq] : iq;
-        const V128 A0 = v_from_uint4(planes[((long)0 * w4) * n + i]);
-        const V128 A1 = v_from_uint4(planes[((long)1 * w4) * n + i]);
-        const V128 B0 = v_from_uint4(planes[((long)2 * w4) * n + i]);
-        const V128 B1 = v_from_uint4(planes[((long)3 * w4) * n + i]);
+        const uint4 a0 = planes[((long)0 * w4) * n + i], a1 = planes[((long)1 * w4) * n + i];
+        const uint4 b0 = planes[((long)2 * w4) * n + i], b1 = planes[((long)3 * w4) * n + i];
         const uint32_t ln = lens[i];
         int m = (int)(ln & 0xffffu), nn = (int)(ln >> 16);
         m = m > 128 ? 128 : m; /* hurdle_matrix.h:626-627 */
         nn = nn > 128 ? 128 : nn;
         const int dest_lane = nn - m;
-        const V128 lo_ = greedy_lane_vector(A0, A1, B0, B1, lane);
-        const V128 lf_ = v_flip_short_hurdles1(lo_);
+        // ---- _construct_hurdles (hurdle_matrix.h:441-455): lane < 0 compares A[i + |lane|] with B[i], lane >= 0 B[i + lane] with A[i]
+        V128 lo_, lf_;
+        {
+            const uint4 xs0 = w_toward0_small(neg ? a0 : b0, sh), xs1 = w_toward0_small(neg ? a1 : b1, sh);
+            const uint4 y0 = neg ? b0 : a0, y1 = neg ? b1 : a1;
+            const uint4 mw = make_uint4((xs0.x ^ y0.x) | (xs1.x ^ y1.x), (xs0.y ^ y0.y) | (xs1.y ^ y1.y), (xs0.z ^ y0.z) | (xs1.z ^ y1.z),
+                                        (xs0.w ^ y0.w) | (xs1.w ^ y1.w));
+            /* flip_short_hurdles(1) (utils.h:200-216): a hurdle survives only next to another one */
+            const uint4 dn = w_toward0_small(mw, 1u);
+            const uint4 up = make_uint4(mw.x << 1, __builtin_amdgcn_alignbit(mw.y, mw.x, 31u), __builtin_amdgcn_alignbit(mw.z, mw.y, 31u),
+                                        __builtin_amdgcn_alignbit(mw.w, mw.z, 31u));
+            lo_ = v_from_words(mw);
+            lf_ = v_from_words(make_uint4(mw.x & (dn.x | up.x), mw.y & (dn.y | up.y), mw.z & (dn.z | up.z), mw.w & (dn.w | up.w)));
+        }
         const int dst = lane_destination(m, nn, lane);
+        const V128 nlf_ = v_not(lf_);
+        const unsigned fb_lf = v_upper_fallback(lf_), fb_nlf = v_upper_fallback(nlf_);
         int sp = -1, len = 0, nsw = 128;
         int cur_lane = 0, cur_col = 0, cost = 0, ncig = 0;
         const long pair = out.index(i);
@@ -538,12 +565,13 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_wave_kernel(const uint4* __r
             bool reach = false;
             int sw = 0, nh = 0;
             const int start_col = cur_col + fwd_col(cur_lane, lane);
+            const int dd = lane - cur_lane;
+            const int adist = dd < 0 ? -dd : dd;
             if (active) {
                 if (sp < start_col) {
-                    const int dd = lane - cur_lane;
-                    nsw = dd < 0 ? -dd : dd;
+                    nsw = adist;
                     int fz, nx;
-                    v_highway_from(lf_, start_col, fz, nx);
+                    v_highway_from_fb(lf_, nlf_, fb_lf, fb_nlf, start_col, fz, nx);
                     sp = start_col + fz;
                     len = nx;
                     if (start_col + fz + nx > dst) {
@@ -552,7 +580,7 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_wave_kernel(const uint4* __r
                         reach = true;
                     }
                 }
-                sw = (semi && guard == 0) ? 0 : lane_penalty(cur_lane, lane, o, e);
+                sw = (semi && guard == 0) ? 0 : (UNIT ? adist : lane_penalty(cur_lane, lane, o, e));
                 nh = v_pop_between(lo_, start_col, sp + len);
             }
             const bool reaching = __ballot(reach) != 0ull;
@@ -599,27 +627,34 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_wave_kernel(const uint4* __r
             // (Needs sw > 0 off cur_lane: not with a free gap-open, and not in SEMI_GLOBAL's first step.)
             int ct = bt;
             if (best_cost > 0 || o <= 0 || (semi && guard == 0)) {
-                const V128 best_vec = v_make(
-                    (u64)(unsigned)lane_read((int)(unsigned)lo_.lo, bt) | ((u64)(unsigned)lane_read((int)(lo_.lo >> 32), bt) << 32),
-                    (u64)(unsigned)lane_read((int)(unsigned)lo_.hi, bt) | ((u64)(unsigned)lane_read((int)(lo_.hi >> 32), bt) << 32));
-                const int best_from_sp = v_ones_from(best_vec, best_sp);
-                int inter = 0x3fffffff, total = 0x3fffffff;
-                if (active && lane != best && !(sp + fwd_col(lane, best) > best_sp)) {
-                    const int endp = sp + len;
-                    inter = sw + nh;
-                    const int tail = x * v_pop_between_pre(best_vec, fwd_col(lane, best) + endp, best_sp, best_from_sp);
-                    total = inter + lane_penalty(lane, best, o, e) + (tail > 0 ? tail : 0);
-                }
-                // The reference folds lanes in ascending order, accepting a lane only if it is no worse than the last
-                // accepted one in both total and intermediate cost.  Thresholds only ever go down from best_cost, so lanes
-                // above it can be dropped up front; the few that remain are folded in lane order with scalar code.
-                unsigned long long cmask = __ballot(total <= best_cost && inter <= best_cost);
-                int small_total = best_cost, small_inter = best_cost;
-                while (cmask) {
-                    const int j = __builtin_ctzll(cmask);
-                    cmask &= cmask - 1ull;
-                    const int tj = lane_read(total, j), ij = lane_read(inter, j);
-                    if (tj <= small_total && ij <= small_inter) small_total = tj, small_inter = ij, ct = j;
+                // first the tests that need nothing of the best lane's vector (:376-377 and the intermediate cost of :388,395):
+                // when no lane passes them the fold accepts nobody, and the tail counts below are not needed
+                const int fb = fwd_col(lane, best);
+                const int inter0 = sw + nh;
+                const bool may = active && lane != best && !(sp + fb > best_sp) && inter0 <= best_cost;
+                if (__ballot(may) != 0ull) {
+                    const V128 best_vec = v_make(
+                        (u64)(unsigned)lane_read((int)(unsigned)lo_.lo, bt) | ((u64)(unsigned)lane_read((int)(lo_.lo >> 32), bt) << 32),
+                        (u64)(unsigned)lane_read((int)(unsigned)lo_.hi, bt) | ((u64)(unsigned)lane_read((int)(lo_.hi >> 32), bt) << 32));
+                    const int best_from_sp = v_ones_from(best_vec, best_sp);
+                    int inter = 0x3fffffff, total = 0x3fffffff;
+                    if (may) {
+                        const int endp = sp + len;
+                        inter = inter0;
+                        const int tail = x * v_pop_between_pre(best_vec, fb + endp, best_sp, best_from_sp);
+                        total = inter + lane_penalty(lane, best, o, e) + (tail > 0 ? tail : 0);
+                    }
+                    // The reference folds lanes in ascending order, accepting a lane only if it is no worse than the last
+                    // accepted one in both total and intermediate cost.  Thresholds only ever go down from best_cost, so lanes
+                    // above it can be dropped up front; the few that remain are folded in lane order with scalar code.
+                    unsigned long long cmask = __ballot(total <= best_cost && inter <= best_cost);
+                    int small_total = best_cost, small_inter = best_cost;
+                    while (cmask) {
+                        const int j = __builtin_ctzll(cmask);
+                        cmask &= cmask - 1ull;
+                        const int tj = lane_read(total, j), ij = lane_read(inter, j);
+                        if (tj <= small_total && ij <= small_inter) small_total = tj, small_inter = ij, ct = j;
+                    }
                 }
             }
             // ---- _step commit (hurdle_matrix.h:411-433) ----
@@ -630,17 +665,24 @@ __global__ __launch_bounds__(ASM_BLOCK) void greedy_wave_kernel(const uint4* __r
             cur_col = new_col;
             if (cur_col >= lane_destination(m, nn, cur_lane)) break;
         }
-        if (t == 0) {
-            // ---- final hop (hurdle_matrix.h:575-590) ----
-            const int dest_col = lane_destination(m, nn, dest_lane);
-            if (cur_lane != dest_lane || cur_col < dest_col) {
-                const V128 dv = greedy_lane_vector(A0, A1, B0, B1, dest_lane);
-                const int sw_f = semi ? 0 : lane_penalty(cur_lane, dest_lane, o, e);
-                const int distance = v_pop_between(dv, cur_col + fwd_col(cur_lane, dest_lane), dest_col);
-                const int hcf = x * distance;
-                cost += sw_f + (hcf > 0 ? hcf : 0);
-                if (cig.on()) cig.step(pair, ncig, cur_lane, dest_lane, distance);
+        // ---- final hop (hurdle_matrix.h:575-590); cur_lane, cur_col, cost and everything below are wave-uniform ----
+        const int dest_col = lane_destination(m, nn, dest_lane);
+        if (cur_lane != dest_lane || cur_col < dest_col) {
+            V128 dv;
+            const int dt = dest_lane + k;
+            if (dt >= 0 && dt < nl) { /* the lane that holds the destination lane's vector */
+                dv = v_make((u64)(unsigned)lane_read((int)(unsigned)lo_.lo, dt) | ((u64)(unsigned)lane_read((int)(lo_.lo >> 32), dt) << 32),
+                            (u64)(unsigned)lane_read((int)(unsigned)lo_.hi, dt) | ((u64)(unsigned)lane_read((int)(lo_.hi >> 32), dt) << 32));
+            } else { /* destination lane outside the band: undefined in the reference, built like a band lane */
+                dv = greedy_lane_vector(v_from_uint4(a0), v_from_uint4(a1), v_from_uint4(b0), v_from_uint4(b1), dest_lane);
             }
+            const int sw_f = semi ? 0 : lane_penalty(cur_lane, dest_lane, o, e);
+            const int distance = v_pop_between(dv, cur_col + fwd_col(cur_lane, dest_lane), dest_col);
+            const int hcf = x * distance;
+            cost += sw_f + (hcf > 0 ? hcf : 0);
+            if (cig.on() && t == 0) cig.step(pair, ncig, cur_lane, dest_lane, distance);
+        }
+        if (t == 0) {
             if (cig.on()) cig.finish(pair, ncig);
             out.put(i, cost);
         }

@@ -87,6 +87,10 @@ inline parasail_result_t* parasail_nw_trace(const char* s1, const int s1Len, con
     asm_batch_free(h, b);
     check(h, rc);
     if (nn == 255) throw std::runtime_error("parasail shim: CIGAR with more than 254 runs");
+    for (int a = 0, z = (int)nn - 1; a < z; a++, z--) { /* the device emits the rows in traceback order: last operation first */
+        const uint16_t tmp = ops[a];
+        ops[a] = ops[z], ops[z] = tmp;
+    }
     char text[8192];
     check(h, asm_cigar_format(ops, nn, ncap, text, sizeof text));
     parasail_result_t* r = (parasail_result_t*)std::malloc(sizeof *r);

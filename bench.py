@@ -31,11 +31,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md §Chip-level parameters)
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")  # workload C2; other workloads: r03_pmc_<workload>.json
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")  # workload C2; other workloads: r04_pmc_<workload>.json
 
 
 def pmc_path(workload):
-    return PMC_FILE if workload == "C2" else os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % workload.lower())
+    return PMC_FILE if workload == "C2" else os.path.join(ROOT, "profiles", "r04_pmc_%s.json" % workload.lower())
 # repack mode of the timed step (ASM_PACK_PIPELINE): "0" -> 1 = strictly in order; "1" -> 2 = pipelined pack (the pack of step
 # s+1 beside the aligners of step s, started behind that step's NW so that it does not keep the persistent Greedy kernel's
 # workgroups off the CUs); "2" -> 3 = overlapped steps (default; as 2, and no step waits for the previous step's Greedy: three

@@ -3,9 +3,9 @@
 set -e
 cd "$(dirname "$0")/.."
 F=gpurun_out/final
-cp $F/r03_pmc.json profiles/r03_pmc.json
-cp $F/valu_rates.txt profiles/r03_valu_rates.txt
-cp $F/bench.json profiles/r03_bench_c2.json
+cp $F/r04_pmc.json profiles/r04_pmc.json
+cp $F/valu_rates.txt profiles/r04_valu_rates.txt
+cp $F/bench.json profiles/r04_bench_c2.json
 S=$(ls $F/stats/*/*kernel_stats.csv $F/stats/*kernel_stats.csv 2>/dev/null | head -1)
-[ -n "$S" ] && cp "$S" profiles/r03_kernel_stats_c2.csv
-ls -la profiles/r03_*
+[ -n "$S" ] && cp "$S" profiles/r04_kernel_stats_c2.csv
+ls -la profiles/r04_*

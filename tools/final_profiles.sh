@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates every number the BENCH line quotes, in one go (on the GPU box, from the repo root):
 #   bash tools/final_profiles.sh <git sha of the tree>
-# 1. tools/pmc_collect.py  -> profiles/r03_pmc.json (HBM bytes, SQ counters, lane utilisation, ubench issue costs + clock)
+# 1. tools/pmc_collect.py  -> profiles/r04_pmc.json (HBM bytes, SQ counters, lane utilisation, ubench issue costs + clock)
 # 2. rocprofv3 --kernel-trace --stats of the bench command -> kernel stats csv
 # 3. python3 bench.py (reads the json written in step 1)   -> the bench line
 # Outputs land in gpurun_out/final/; copy what is to be judged into profiles/ (tools/copy_profiles.sh).

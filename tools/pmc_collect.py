@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Collects every counter bench.py's `roofline` quotes and WRITES profiles/r03_pmc.json itself (run on the GPU box from the
+"""Collects every counter bench.py's `roofline` quotes and WRITES profiles/r04_pmc.json itself (run on the GPU box from the
 repo root: `python3 tools/pmc_collect.py --head <git sha> [--workload C2]`).
 
 Passes, each its own rocprofv3 run over bench.py (counters never share a run with tracing, and FETCH_SIZE / WRITE_SIZE do not
@@ -139,7 +139,7 @@ def add_mixes(kernels, ubench):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--remix", action="store_true",
-                    help="no GPU: recompute the per-kernel instruction-mix costs of an existing profiles/r03_pmc.json (same sources)")
+                    help="no GPU: recompute the per-kernel instruction-mix costs of an existing profiles/r04_pmc.json (same sources)")
     ap.add_argument("--head", default="unknown", help="git HEAD of the tree being measured (the box has no .git)")
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--steps", type=int, default=5)
@@ -205,7 +205,7 @@ def main():
     with open(os.path.join(ROOT, "gpurun_out", "final", "valu_rates.txt"), "w") as fh:
         fh.write(txt)
     ub = json.loads(txt.strip().splitlines()[-1][len("JSON "):])
-    ubench = {"sclk_hz": ub["sclk_hz_median"], "rows": ub["rows"], "source": "tools/ubench/valu_rates.hip (profiles/r03_valu_rates.txt)"}
+    ubench = {"sclk_hz": ub["sclk_hz_median"], "rows": ub["rows"], "source": "tools/ubench/valu_rates.hip (profiles/r04_valu_rates.txt)"}
     add_mixes(kernels, ubench)
     doc = {"_comment": "written by tools/pmc_collect.py; HBM bytes = FETCH_SIZE KiB x 2 (gfx950 tallies 128-B requests at 64 B for "
                        "wide coalesced reads) + WRITE_SIZE KiB, per launch, mean over the launches of the run",
