@@ -18,7 +18,13 @@ struct G3LdsTable {
     __device__ __forceinline__ uint2 get(uint32_t i) const { return t[i]; }
 };
 
-constexpr size_t g3_lds_bytes(int K, int NT) { return (size_t)G3_TABLE_ENTRIES * 8 + (size_t)(2 * K + 1) * NT * 16; }
+/* costs of the workgroup's slice staged in LDS and written out in one coalesced sweep at the end (when the slice fits and the
+ * results go to their own index): a refilling lane's scattered 4-byte store — 2.5 x write amplification at C2, 64-bit address
+ * arithmetic inside the half-empty refill block — becomes one ds_write_b32 */
+#define G3_STAGE_ENTRIES 4096
+constexpr size_t g3_lds_bytes(int K, int NT) {
+    return (size_t)G3_TABLE_ENTRIES * 8 + (size_t)(2 * K + 1) * NT * 16 + (size_t)G3_STAGE_ENTRIES * 4;
+}
 
 __device__ __forceinline__ G3V g3_from_uint4(uint4 q) {
     G3V r;
@@ -36,6 +42,7 @@ __global__ __launch_bounds__(NT) void greedy_fast_kernel(const uint4* __restrict
     extern __shared__ uint4 g3_smem[];
     uint2* const tab = reinterpret_cast<uint2*>(g3_smem);
     G3V* const vecs = reinterpret_cast<G3V*>(g3_smem + G3_TABLE_ENTRIES / 2);
+    int32_t* const stage = reinterpret_cast<int32_t*>(vecs + (size_t)NL * NT);
     for (int i = threadIdx.x; i < G3_TABLE_ENTRIES / 2; i += NT) g3_smem[i] = reinterpret_cast<const uint4*>(table_g)[i];
     __syncthreads();
     const G3LdsTable table{tab};
@@ -60,10 +67,9 @@ __global__ __launch_bounds__(NT) void greedy_fast_kernel(const uint4* __restrict
     // (Measured and dropped: handing the last 8-25 % of the batch out dynamically, in chunks of 128 pairs from a counter in device
     // memory, so that workgroups which are ahead take more — 0.145 ms against 0.113: the atomics' round trips stall the refills.)
     __shared__ unsigned int g3_next, g3_end;
-    if (threadIdx.x == 0) {
-        const long lo = n * (long)blockIdx.x / (long)gridDim.x, hi = n * ((long)blockIdx.x + 1) / (long)gridDim.x;
-        g3_next = (unsigned int)lo, g3_end = (unsigned int)hi;
-    }
+    const long slice_lo = n * (long)blockIdx.x / (long)gridDim.x, slice_hi = n * ((long)blockIdx.x + 1) / (long)gridDim.x;
+    const bool staged = out.order == nullptr && slice_hi - slice_lo <= (long)G3_STAGE_ENTRIES; /* workgroup-uniform */
+    if (threadIdx.x == 0) g3_next = (unsigned int)slice_lo, g3_end = (unsigned int)slice_hi;
     __syncthreads();
 #ifdef GREEDY_DIAG
     unsigned long long dg_refill = 0, dg_step = 0, dg_iters = 0, dg_lanes = 0, dg_t0 = __builtin_amdgcn_s_memtime();
@@ -106,7 +112,8 @@ __global__ __launch_bounds__(NT) void greedy_fast_kernel(const uint4* __restrict
                     if (cig.on()) cig.step(pair, ncig, s.cur_lane, s.dest_lane, distance); /* the hurdle count (:589) */
                 }
                 if (cig.on()) cig.finish(pair, ncig);
-                out.put(idx, s.cost);
+                if (staged) stage[idx - slice_lo] = s.cost;
+                else out.put(idx, s.cost);
             }
             long got = -1;
             { /* consecutive pairs for the lanes that need one: rank inside the wave + the workgroup's counter */
@@ -145,6 +152,10 @@ __global__ __launch_bounds__(NT) void greedy_fast_kernel(const uint4* __restrict
 #ifdef GREEDY_DIAG
         dg_step += __builtin_amdgcn_s_memtime() - dg_b;
 #endif
+    }
+    if (staged) { /* every wave leaves the loop through its break: the whole workgroup meets here */
+        __syncthreads();
+        for (long q = threadIdx.x; q < slice_hi - slice_lo; q += NT) out.out[slice_lo + q] = stage[q];
     }
 #ifdef GREEDY_DIAG
     if ((threadIdx.x & 63) == 0 && cig.nops != nullptr && cig.ops == nullptr) { /* diag build: cig.nops doubles as the debug buffer */

@@ -601,6 +601,39 @@ ASM_DEV int vw_next_one(const VW<W64>& v, int from) {
     return from >= W64 * 64 ? W64 * 64 : res;
 }
 
+// The same scan for a caller that keeps, per vector, "first set bit in the words above word q" (W64 * 64 when none) for every q
+// but the last: v_ffbl_b32 gives 0xFFFFFFFF for an empty word, and with saturating adds an empty shifted word turns into a candidate
+// that loses the final min — no zero tests, no compare-and-select chain behind the shift (asm_bits.h, v_next_one_from_fb).
+template <int W64>
+struct VWAbove {
+    unsigned fb[W64 > 1 ? W64 - 1 : 1];
+};
+template <int W64>
+ASM_DEV VWAbove<W64> vw_above(const VW<W64>& v) {
+    VWAbove<W64> r;
+    unsigned run = W64 * 64u;
+#pragma unroll
+    for (int q = W64 - 2; q >= 0; q--) {
+        run = v.w[q + 1] ? (unsigned)(q + 1) * 64u + (unsigned)__builtin_ctzll(v.w[q + 1]) : run;
+        r.fb[q] = run;
+    }
+    return r;
+}
+template <int W64>
+ASM_DEV int vw_next_one_fb(const VW<W64>& v, const VWAbove<W64>& ab, int from) { /* = vw_next_one(v, from) for from >= 0 */
+    u64 x = v.w[W64 - 1];
+    unsigned f = W64 * 64u;
+#pragma unroll
+    for (int q = W64 - 2; q >= 0; q--) { /* the nested tests leave the word `from` falls into, and what lies above it */
+        const bool below = from < (q + 1) * 64;
+        x = below ? v.w[q] : x;
+        f = below ? ab.fb[q] : f;
+    }
+    const u64 y = x >> (from & 63);
+    const unsigned c = min(v_ffbl_raw((unsigned)y), __builtin_elementwise_add_sat(v_ffbl_raw((unsigned)(y >> 32)), 32u));
+    return (int)min(__builtin_elementwise_add_sat((unsigned)from, c), f);
+}
+
 // bit p of the result = bit (p - s) of v (bits move away from index 0), s in [0, 63]
 template <int W64>
 ASM_DEV VW<W64> vw_away0_small(const VW<W64>& v, int s) {
@@ -689,6 +722,9 @@ ASM_DEV int leap_unit_pair(const uint4* __restrict__ planes, const uint32_t* __r
     int en[NL];
 #pragma unroll
     for (int j = 0; j < NL; j++) en[j] = -2;
+    VWAbove<W64> above[NL];
+#pragma unroll
+    for (int j = 0; j < NL; j++) above[j] = vw_above<W64>(mask[j]);
 
     int result = -1;
     // e = 0: only the main diagonal is live in ED_GLOBAL (LV_BAG.cpp:102-104,131-147)
@@ -713,9 +749,11 @@ ASM_DEV int leap_unit_pair(const uint4* __restrict__ planes, const uint32_t* __r
             int enew = -2;
             if (st >= 0) {
                 const int from = st > len ? len : st;
-                int t = vw_next_one<W64>(mask[j], from); /* count_ID_length, :9-23 */
+                /* count_ID_length (:9-23) as a saturating scan: first mismatch at or after `from`, capped at len; enew = max(t, st)
+                 * is the reference's "a start beyond the end stays where it is" (t >= from = st whenever st <= len) */
+                int t = vw_next_one_fb<W64>(mask[j], above[j], from);
                 t = t > len ? len : t;
-                enew = st > len ? st : t;
+                enew = t > st ? t : st;
                 if (enew == len) { /* :220-238 */
                     const int diff = d < 0 ? -d : d;
                     const int conv = e + diff; /* o + (diff-1)*ext with o = ext = 1 */
@@ -838,6 +876,9 @@ __global__ __launch_bounds__(LEAP_GEN_THREADS) void leap_general_kernel(const ui
     VW<W64> mask[NL];
 #pragma unroll
     for (int j = 0; j < NL; j++) mask[j] = leap_lane_mask<W64>(A0, A1, B0, B1, VA, VB, j - K);
+    VWAbove<W64> above[NL]; /* the saturating scan's fall-backs (vw_next_one_fb) */
+#pragma unroll
+    for (int j = 0; j < NL; j++) above[j] = vw_above<W64>(mask[j]);
 
     int result = -1;
     // e = 0: only the main diagonal is live (LV_BAG.cpp:102-104,131-147)
@@ -888,9 +929,9 @@ __global__ __launch_bounds__(LEAP_GEN_THREADS) void leap_general_kernel(const ui
             int enew = -2;
             if (st >= 0) {
                 const int from = st > len ? len : st;
-                int r = vw_next_one<W64>(mask[j], from); /* count_ID_length, :9-23 */
+                int r = vw_next_one_fb<W64>(mask[j], above[j], from); /* count_ID_length, :9-23 */
                 r = r > len ? len : r;
-                enew = st > len ? st : r;
+                enew = r > st ? r : st; /* st beyond the end stays st (r >= from = st otherwise) */
                 if (enew == len) { /* :220-238 */
                     const int diff = d < 0 ? -d : d;
                     const int conv = e + (diff ? o + (diff - 1) * ext : 0);
