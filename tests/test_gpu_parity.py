@@ -933,6 +933,20 @@ def test_batches_may_outlive_their_engine(asm):
     eng2 = asm.Engine(0)
     assert eng2.align(eng2.generate(cfg, 0, 100), asm.NW, params).shape == (100,)
     eng2.close()
+    # A stale batch freed while a NEW engine is alive — which the allocator likes to put at the destroyed engine's address: the
+    # batch names its owner by (address, serial), so its release must not reach into the new engine's pool.
+    for _ in range(4):
+        a = asm.Engine(0)
+        stale = a.generate(cfg, 0, 3000)
+        a.close()
+        b = asm.Engine(0)
+        live = b.generate(cfg, 7, 3000)
+        want = b.align(live, asm.GREEDY, params)
+        stale.free()                      # owner gone: only the record is dropped
+        again = b.generate(cfg, 7, 3000)  # would be handed a block of `live` if the stale release had idled one
+        assert np.array_equal(b.align(live, asm.GREEDY, params), want)
+        assert np.array_equal(b.align(again, asm.GREEDY, params), want)
+        b.close()
 
 
 @pytest.mark.parametrize("k", [1, 2, 3])

@@ -24,7 +24,7 @@ case $PART in
 c2)
   python3 tools/pmc_collect.py --head $HEAD > $O/pmc_collect_c2.log 2>&1; echo "pmc c2 done"
   cp gpurun_out/final/valu_rates.txt $O/valu_rates.txt
-  stats c2 --steps 24 --warmup 2 --no-cpu-baseline --no-standalone --no-sequential --no-in-order
+  stats c2 --steps 200 --warmup 2 --no-cpu-baseline --no-standalone --no-sequential --no-in-order
   python3 bench.py > $O/bench_c2.json 2> $O/bench_c2.err; echo "bench c2 done"; tail -c 600 $O/bench_c2.json ;;
 c3|c4|c5)
   W=$(echo $PART | tr a-z A-Z)

@@ -1,30 +1,49 @@
 #!/usr/bin/env python3
 """Re-wraps the prose of a markdown file to at most 120 columns (development tool: `python tools/reflow_md.py FILE...`).
-Table rows, fenced code, headings and lines that are short enough are left alone; a list item's continuation lines are
-indented to its text."""
+Paragraphs and list items that hold a line longer than that are joined and wrapped again as a whole (a list item's
+continuation lines are indented to its text); table rows, fenced code, headings and blocks that already fit are left alone."""
 import re
 import sys
 import textwrap
 
 WIDTH = 120
+BULLET = re.compile(r"^(\s*)((?:[-*+]|\d+\.)\s+)")
 
 
 def reflow(text):
-    out, fence = [], False
-    for line in text.split("\n"):
-        if line.lstrip().startswith("```"):
+    lines = text.split("\n")
+    out, i, fence = [], 0, False
+
+    def special(l):
+        return (not l.strip()) or l.lstrip().startswith(("|", "#", "```", ">")) or l.strip() in ("---", "***")
+
+    while i < len(lines):
+        l = lines[i]
+        if l.lstrip().startswith("```"):
             fence = not fence
-            out.append(line)
+            out.append(l)
+            i += 1
             continue
-        if fence or len(line) <= WIDTH or line.lstrip().startswith(("|", "#")):
-            out.append(line)
+        if fence or special(l):
+            out.append(l)
+            i += 1
             continue
-        m = re.match(r"^(\s*)((?:[-*+]|\d+\.)\s+)?", line)
-        indent, bullet = m.group(1), m.group(2) or ""
-        body = line[len(indent) + len(bullet):]
-        wrapped = textwrap.wrap(body, width=WIDTH - len(indent) - len(bullet), break_long_words=False, break_on_hyphens=False)
-        for i, w in enumerate(wrapped):
-            out.append(indent + (bullet if i == 0 else " " * len(bullet)) + w)
+        # a block: this line and the following lines that continue it (not blank, not special, not a new list item)
+        j = i + 1
+        while j < len(lines) and not special(lines[j]) and not BULLET.match(lines[j]):
+            j += 1
+        block = lines[i:j]
+        if max(len(b) for b in block) <= WIDTH:
+            out += block
+        else:
+            m = BULLET.match(block[0])
+            indent = m.group(1) if m else re.match(r"^\s*", block[0]).group(0)
+            bullet = m.group(2) if m else ""
+            body = " ".join([block[0][len(indent) + len(bullet):].strip()] + [b.strip() for b in block[1:]])
+            wrapped = textwrap.wrap(body, width=WIDTH - len(indent) - len(bullet), break_long_words=False, break_on_hyphens=False)
+            for k, w in enumerate(wrapped):
+                out.append(indent + (bullet if k == 0 else " " * len(bullet)) + w)
+        i = j
     return "\n".join(out)
 
 
@@ -32,6 +51,7 @@ if __name__ == "__main__":
     for path in sys.argv[1:]:
         with open(path) as fh:
             src = fh.read()
+        res = reflow(src)
         with open(path, "w") as fh:
-            fh.write(reflow(src))
-        print(path, "max line", max(len(l) for l in reflow(src).split("\n")))
+            fh.write(res)
+        print(path, "max line", max(len(l) for l in res.split("\n")))
