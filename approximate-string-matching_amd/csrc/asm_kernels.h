@@ -604,6 +604,11 @@ ASM_DEV int vw_next_one(const VW<W64>& v, int from) {
 // The same scan for a caller that keeps, per vector, "first set bit in the words above word q" (W64 * 64 when none) for every q
 // but the last: v_ffbl_b32 gives 0xFFFFFFFF for an empty word, and with saturating adds an empty shifted word turns into a candidate
 // that loses the final min — no zero tests, no compare-and-select chain behind the shift (asm_bits.h, v_next_one_from_fb).
+/* Up to three words per vector the fall-backs cost no registers the compiler was not already spending (it hoists the upper
+ * words' ctz out of the generation loop either way: 59 and 90 VGPRs before and after at two and three words).  From four words
+ * on they do — 120 -> 146 and 165 -> 209 VGPRs at four and six words, a wave per SIMD less — and the wider classes of C5 lost
+ * what the shorter scan gained: those keep vw_next_one. */
+#define VW_SCAN_FB(W64) ((W64) <= 3)
 template <int W64>
 struct VWAbove {
     unsigned fb[W64 > 1 ? W64 - 1 : 1];
@@ -751,7 +756,7 @@ ASM_DEV int leap_unit_pair(const uint4* __restrict__ planes, const uint32_t* __r
                 const int from = st > len ? len : st;
                 /* count_ID_length (:9-23) as a saturating scan: first mismatch at or after `from`, capped at len; enew = max(t, st)
                  * is the reference's "a start beyond the end stays where it is" (t >= from = st whenever st <= len) */
-                int t = vw_next_one_fb<W64>(mask[j], above[j], from);
+                int t = VW_SCAN_FB(W64) ? vw_next_one_fb<W64>(mask[j], above[j], from) : vw_next_one<W64>(mask[j], from);
                 t = t > len ? len : t;
                 enew = t > st ? t : st;
                 if (enew == len) { /* :220-238 */
@@ -929,7 +934,7 @@ __global__ __launch_bounds__(LEAP_GEN_THREADS) void leap_general_kernel(const ui
             int enew = -2;
             if (st >= 0) {
                 const int from = st > len ? len : st;
-                int r = vw_next_one_fb<W64>(mask[j], above[j], from); /* count_ID_length, :9-23 */
+                int r = VW_SCAN_FB(W64) ? vw_next_one_fb<W64>(mask[j], above[j], from) : vw_next_one<W64>(mask[j], from); /* count_ID_length, :9-23 */
                 r = r > len ? len : r;
                 enew = r > st ? r : st; /* st beyond the end stays st (r >= from = st otherwise) */
                 if (enew == len) { /* :220-238 */
