@@ -485,7 +485,11 @@ def run(args, asm, eng, torch, dist, stream, rank, world, cfg, params, first, n,
     out = {
         "metric": "alignments/sec (1e6-pair batch, 100bp, err=0.10) per GPU; NW penalty bit-exact %",
         "value": value,
-        "unit": "read pairs/s through NW+LEAP+Greedy (whole job)",
+        "unit": "read pairs/s through " + "+".join(asm.ALIGNER_NAMES[a].upper() if a == asm.NW else asm.ALIGNER_NAMES[a].capitalize()
+                                                   for a in aligners)
+                + " (whole job; consecutive steps " + ("overlap" if steps_form(asm, aligners, params) == 3 else
+                                                        "pipeline their pack" if steps_form(asm, aligners, params) == 2 else "run in order")
+                + ", inputs rotate over resident batches; value_in_order = the same steps strictly in order)",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
@@ -506,6 +510,7 @@ def run(args, asm, eng, torch, dist, stream, rank, world, cfg, params, first, n,
                         f"({len(batches) * batch.ascii_bytes / 2**20:.0f} MiB of ASCII against a 256 MiB Infinity Cache)",
         },
         "ms_per_step_in_order": in_order_ms,
+        "value_in_order": ((args.total_pairs if args.total_pairs else world * n) / (in_order_ms * 1e-3)) if in_order_ms else None,
         "ms_per_step_same_batch": same_batch_ms,
         "pack_GBps": {"rotating": pack_gbps(batch, n, kernel_ms.get("pack")),
                       "same_batch": pack_gbps(batch, n, kernel_ms_same.get("pack")),

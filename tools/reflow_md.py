@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Re-wraps the prose of a markdown file to at most 120 columns (development tool: `python tools/reflow_md.py FILE...`).
 Paragraphs and list items that hold a line longer than that are joined and wrapped again as a whole (a list item's
-continuation lines are indented to its text); table rows, fenced code, headings and blocks that already fit are left alone."""
+continuation lines are indented to its text); table rows, fenced code, headings and blocks that already fit are left alone
+(`--all`: every paragraph is wrapped again)."""
 import re
 import sys
 import textwrap
@@ -10,7 +11,7 @@ WIDTH = 120
 BULLET = re.compile(r"^(\s*)((?:[-*+]|\d+\.)\s+)")
 
 
-def reflow(text):
+def reflow(text, force=False):
     lines = text.split("\n")
     out, i, fence = [], 0, False
 
@@ -33,7 +34,7 @@ def reflow(text):
         while j < len(lines) and not special(lines[j]) and not BULLET.match(lines[j]):
             j += 1
         block = lines[i:j]
-        if max(len(b) for b in block) <= WIDTH:
+        if not force and max(len(b) for b in block) <= WIDTH:
             out += block
         else:
             m = BULLET.match(block[0])
@@ -48,10 +49,11 @@ def reflow(text):
 
 
 if __name__ == "__main__":
-    for path in sys.argv[1:]:
+    force = "--all" in sys.argv  # re-wrap every paragraph, also those that already fit
+    for path in [a for a in sys.argv[1:] if a != "--all"]:
         with open(path) as fh:
             src = fh.read()
-        res = reflow(src)
+        res = reflow(src, force)
         with open(path, "w") as fh:
             fh.write(res)
         print(path, "max line", max(len(l) for l in res.split("\n")))
