@@ -96,6 +96,8 @@ def pmc_for(pmc, short, pairs):
         if k.get(key) is not None:
             out[key] = k[key] * scale
     out["valu_mix"] = k.get("valu_mix")
+    if k.get("members"):  # a mixed-length batch: one kernel per width class, counters summed over the family
+        out["members"] = [m["kernel_name"] for m in k["members"]]
     return out
 
 
@@ -541,6 +543,7 @@ def run(args, asm, eng, torch, dist, stream, rank, world, cfg, params, first, n,
             "traffic": entry.get("traffic_bytes") if entry else None,
             "traffic_source": (entry or {}).get("source") or pmc_why,
             "traffic_kernel": (entry or {}).get("kernel_name"),
+            "traffic_kernels_summed": (entry or {}).get("members"),
             "algorithmic_bytes_per_launch": alg_bytes,
             "avg_launch_ms": region_ms[dom],
             "note": "avg_launch_ms: HIP events on the launching stream inside the timed region, where this kernel shares the "

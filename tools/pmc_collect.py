@@ -37,16 +37,17 @@ PASSES = {
 }
 
 
-def run_pass(name, counters, out_dir, bench_args):
+def run_pass(name, counters, out_dir, bench_args, reuse=False):
     d = os.path.join(out_dir, name)
-    shutil.rmtree(d, ignore_errors=True)
-    env = dict(os.environ, TMPDIR="/tmp")
-    cmd = ["rocprofv3", "--pmc", *counters, "--output-format", "csv", "-d", d, "--", sys.executable,
-           os.path.join(ROOT, "bench.py"), *bench_args]
-    with open(os.path.join(out_dir, name + ".log"), "w") as log:
-        r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT, timeout=1500)
-    if r.returncode != 0:
-        raise SystemExit(f"pass {name} failed (rc {r.returncode}); see {out_dir}/{name}.log")
+    if not reuse:
+        shutil.rmtree(d, ignore_errors=True)
+        env = dict(os.environ, TMPDIR="/tmp")
+        cmd = ["rocprofv3", "--pmc", *counters, "--output-format", "csv", "-d", d, "--", sys.executable,
+               os.path.join(ROOT, "bench.py"), *bench_args]
+        with open(os.path.join(out_dir, name + ".log"), "w") as log:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT, timeout=1500)
+        if r.returncode != 0:
+            raise SystemExit(f"pass {name} failed (rc {r.returncode}); see {out_dir}/{name}.log")
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(f) as fh:
@@ -129,8 +130,23 @@ def isa_mix(kernel_name, rows):
 
 
 def add_mixes(kernels, ubench):
-    """Every measured kernel gets the issue cost of ITS instruction mix (static histogram x ubench rows)."""
+    """Every measured kernel gets the issue cost of ITS instruction mix (static histogram x ubench rows); a family of width-class
+    kernels the instruction-weighted mean of its members' mixes."""
     for short, e in kernels.items():
+        members = e.get("members")
+        if members:
+            tot = w = 0.0
+            for m in members:
+                mix = isa_mix(m["kernel_name"], ubench["rows"])
+                if mix and mix.get("cycles_per_inst_mix") and m.get("insts_valu"):
+                    m["cycles_per_inst_mix"] = mix["cycles_per_inst_mix"]
+                    tot += m["insts_valu"]
+                    w += m["insts_valu"] * mix["cycles_per_inst_mix"]
+            if tot:
+                e["valu_mix"] = {"cycles_per_inst_mix": w / tot,
+                                 "note": "instruction-weighted mean over the family's width-class kernels (`members`), each a static "
+                                         "histogram of its ISA priced with the ubench rows"}
+            continue
         mix = isa_mix(e["kernel_name"], ubench["rows"])
         if mix:
             e["valu_mix"] = mix
@@ -140,6 +156,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--remix", action="store_true",
                     help="no GPU: recompute the per-kernel instruction-mix costs of an existing profiles/r04_pmc.json (same sources)")
+    ap.add_argument("--from-raw", action="store_true",
+                    help="no GPU: rebuild the json from the raw rocprofv3 output of the last run (gpurun_out/final/pmc) and the ubench "
+                         "rows of the existing json (same workload, same sources)")
     ap.add_argument("--head", default="unknown", help="git HEAD of the tree being measured (the box has no .git)")
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--steps", type=int, default=5)
@@ -162,50 +181,72 @@ def main():
     os.makedirs(out_dir, exist_ok=True)
     bench_args = ["--workload", args.workload, "--steps", str(args.steps), "--warmup", "1", "--no-cpu-baseline",
                   "--no-sequential", "--no-standalone", "--no-in-order"] + (["--pairs", str(args.pairs)] if args.pairs else [])
-    data = {name: run_pass(name, ctrs, out_dir, bench_args) for name, ctrs in PASSES.items()}
+    data = {name: run_pass(name, ctrs, out_dir, bench_args, reuse=args.from_raw) for name, ctrs in PASSES.items()}
 
     import approximate_string_matching_amd as asm
 
     _, n_default, _ = asm.workload(args.workload)
     pairs = args.pairs or min(n_default, 1_000_000)
+    keys = {"insts_valu": ("sq_a", "SQ_INSTS_VALU"), "insts_salu": ("sq_a", "SQ_INSTS_SALU"),
+            "active_inst_valu": ("sq_a", "SQ_ACTIVE_INST_VALU"), "wave_cycles": ("sq_a", "SQ_WAVE_CYCLES"),
+            "waves": ("sq_a", "SQ_WAVES"), "wait_any": ("sq_a", "SQ_WAIT_ANY"),
+            "wait_inst_any": ("sq_a", "SQ_WAIT_INST_ANY"), "active_inst_any": ("sq_a", "SQ_ACTIVE_INST_ANY"),
+            "thread_cycles_valu": ("sq_b", "SQ_THREAD_CYCLES_VALU"), "busy_cycles": ("sq_b", "SQ_BUSY_CYCLES"),
+            "insts_vmem_rd": ("sq_b", "SQ_INSTS_VMEM_RD"), "insts_lds": ("sq_b", "SQ_INSTS_LDS"),
+            "grbm_gui_active": ("sq_b", "GRBM_GUI_ACTIVE")}
     kernels = {}
     for short, prefix in FAMILIES:
-        # the family's kernel of the timed region = the one launched most often
+        # The family's kernels of the timed region = those launched most often.  A mixed-length batch launches one kernel per
+        # width class, all equally often: their counters are SUMMED (the bench line divides them by the family's time), the
+        # member with the most VALU instructions lends its name, and `members` lists every one of them.
         cand = [(len(v.get("SQ_WAVES", [])), k) for k, v in data["sq_a"].items() if prefix in k.split("(")[0]]
         if not cand:
             continue
-        _, name = max(cand)
-        mean = lambda p, c: (sum(data[p][name][c]) / len(data[p][name][c])) if data[p].get(name, {}).get(c) else None  # noqa: E731
-        fetch_kib, write_kib = mean("fetch", "FETCH_SIZE"), mean("write", "WRITE_SIZE")
-        e = {"kernel_name": name.split("(")[0].replace("void ", ""), "launches": len(data["sq_a"][name]["SQ_WAVES"]),
-             "fetch_kib_raw": fetch_kib, "write_kib": write_kib,
-             "fetch_bytes": fetch_kib * 1024 * 2 if fetch_kib is not None else None,
-             "write_bytes": write_kib * 1024 if write_kib is not None else None}
-        if fetch_kib is not None and write_kib is not None:
-            e["traffic_bytes"] = e["fetch_bytes"] + e["write_bytes"]
-        for key, (p, c) in {"insts_valu": ("sq_a", "SQ_INSTS_VALU"), "insts_salu": ("sq_a", "SQ_INSTS_SALU"),
-                            "active_inst_valu": ("sq_a", "SQ_ACTIVE_INST_VALU"), "wave_cycles": ("sq_a", "SQ_WAVE_CYCLES"),
-                            "waves": ("sq_a", "SQ_WAVES"), "wait_any": ("sq_a", "SQ_WAIT_ANY"),
-                            "wait_inst_any": ("sq_a", "SQ_WAIT_INST_ANY"), "active_inst_any": ("sq_a", "SQ_ACTIVE_INST_ANY"),
-                            "thread_cycles_valu": ("sq_b", "SQ_THREAD_CYCLES_VALU"), "busy_cycles": ("sq_b", "SQ_BUSY_CYCLES"),
-                            "insts_vmem_rd": ("sq_b", "SQ_INSTS_VMEM_RD"), "insts_lds": ("sq_b", "SQ_INSTS_LDS"),
-                            "grbm_gui_active": ("sq_b", "GRBM_GUI_ACTIVE")}.items():
-            e[key] = mean(p, c)
+        top = max(c for c, _ in cand)
+        names = sorted(k for c, k in cand if c == top)
+        mean = lambda p, c, name: (sum(data[p][name][c]) / len(data[p][name][c])) if data[p].get(name, {}).get(c) else None  # noqa: E731
+        member = {}
+        for name in names:
+            fetch_kib, write_kib = mean("fetch", "FETCH_SIZE", name), mean("write", "WRITE_SIZE", name)
+            m = {"kernel_name": name.split("(")[0].replace("void ", ""), "launches": top, "fetch_kib_raw": fetch_kib, "write_kib": write_kib,
+                 "fetch_bytes": fetch_kib * 1024 * 2 if fetch_kib is not None else None,
+                 "write_bytes": write_kib * 1024 if write_kib is not None else None}
+            if fetch_kib is not None and write_kib is not None:
+                m["traffic_bytes"] = m["fetch_bytes"] + m["write_bytes"]
+            for key, (p, c) in keys.items():
+                m[key] = mean(p, c, name)
+            member[name] = m
+        lead = max(names, key=lambda k: member[k].get("insts_valu") or 0)
+        e = dict(member[lead])
+        if len(names) > 1:
+            for key in list(e):
+                if key in ("kernel_name", "launches"):
+                    continue
+                vals = [member[k].get(key) for k in names]
+                e[key] = sum(vals) if all(v is not None for v in vals) else None
+            e["members"] = [{"kernel_name": member[k]["kernel_name"], "insts_valu": member[k].get("insts_valu"),
+                             "traffic_bytes": member[k].get("traffic_bytes")} for k in names]
         if e.get("thread_cycles_valu") and e.get("active_inst_valu"):
             e["lane_util"] = e["thread_cycles_valu"] / (64.0 * e["active_inst_valu"])
         kernels[short] = e
         print(short, json.dumps(e), flush=True)
 
     # issue costs + clock
-    ub_dir = os.path.join(ROOT, "tools", "ubench")
-    exe = os.path.join(ub_dir, "valu_rates")
-    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(exe + ".hip"):
-        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-Wno-unused-value", "-o", exe, exe + ".hip"], check=True)
-    txt = subprocess.run([exe], capture_output=True, text=True, check=True, timeout=600).stdout
-    with open(os.path.join(ROOT, "gpurun_out", "final", "valu_rates.txt"), "w") as fh:
-        fh.write(txt)
-    ub = json.loads(txt.strip().splitlines()[-1][len("JSON "):])
-    ubench = {"sclk_hz": ub["sclk_hz_median"], "rows": ub["rows"], "source": "tools/ubench/valu_rates.hip (profiles/r04_valu_rates.txt)"}
+    if args.from_raw:
+        with open(bench.pmc_path(args.workload)) as fh:
+            prev = json.load(fh)
+        ubench = prev["ubench"]
+        args.head = prev.get("git_head", args.head)
+    else:
+        ub_dir = os.path.join(ROOT, "tools", "ubench")
+        exe = os.path.join(ub_dir, "valu_rates")
+        if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(exe + ".hip"):
+            subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-Wno-unused-value", "-o", exe, exe + ".hip"], check=True)
+        txt = subprocess.run([exe], capture_output=True, text=True, check=True, timeout=600).stdout
+        with open(os.path.join(ROOT, "gpurun_out", "final", "valu_rates.txt"), "w") as fh:
+            fh.write(txt)
+        ub = json.loads(txt.strip().splitlines()[-1][len("JSON "):])
+        ubench = {"sclk_hz": ub["sclk_hz_median"], "rows": ub["rows"], "source": "tools/ubench/valu_rates.hip (profiles/r04_valu_rates.txt)"}
     add_mixes(kernels, ubench)
     doc = {"_comment": "written by tools/pmc_collect.py; HBM bytes = FETCH_SIZE KiB x 2 (gfx950 tallies 128-B requests at 64 B for "
                        "wide coalesced reads) + WRITE_SIZE KiB, per launch, mean over the launches of the run",
