@@ -306,7 +306,9 @@ int asm_accuracy_async(asm_handle* h, const int32_t* d_nw, const int32_t* d_leap
  * them).  The caller ALTERNATES between two sets of output arrays from call to call (a set is written again two calls later,
  * when the library has seen its counters finish), and calls asm_pipeline_join_async before it touches the batch or the outputs
  * in any other way.  A later call with repack != 3 joins by itself.  Passing the previous overlapped call's arrays again without a
- * join in between is refused (ASM_EINVAL). */
+ * join in between is refused (ASM_EINVAL).  Consecutive calls may name DIFFERENT batches (a caller rotating over several resident
+ * batches): they are paced like calls on one batch — the pack of call c starts behind the counters of call c - 2.  A call that
+ * cannot overlap (the Greedy-first shape above, an empty batch) runs as repack = 2, ordered behind every earlier call. */
 int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, int repack, int32_t* d_nw,
                             int32_t* d_leap, int32_t* d_greedy, const int32_t* d_answers,
                             unsigned long long* d_counters);
