@@ -871,6 +871,40 @@ def test_overlapped_calls_give_the_same_results(asm, engine, oracle, wl, n):
         engine.free(x)
 
 
+def test_overlapped_calls_followed_by_a_call_that_cannot_overlap(asm, engine, oracle):
+    """A run of overlapped calls (repack = 3) and then, WITHOUT a join, a call asking for the same form that cannot have it: the
+    Greedy-first shape of config 3 (LEAP + Greedy without NW at a wide band: LEAP is scheduled by Greedy's penalties) and an empty
+    batch.  The library runs those as pipelined-pack calls behind everything enqueued before; the misuse guard starts afresh; the
+    counters of both kinds of call add up exactly (total_tests counts without NW too)."""
+    cfg2, _, p2 = asm.workload("C2")
+    cfg3, _, p3 = asm.workload("C3")
+    n2, n3 = 40_000, 6_000
+    hb2, hb3 = asm.generate_pairs(cfg2, 5, n2), asm.generate_pairs(cfg3, 6, n3)
+    b2, b3 = engine.upload(hb2, asm.GREEDY_CLEAN), engine.upload(hb3, asm.GREEDY_CLEAN)
+    empty = engine.upload(asm.HostBatch.from_strings([]), asm.GREEDY_CLEAN)
+    sets = [[engine.malloc(4 * n2) for _ in range(3)] for _ in range(2)]
+    o3 = [engine.malloc(4 * n3) for _ in range(2)]
+    d_cnt = engine.malloc(32)
+    engine.memset_async(d_cnt, 0, 32)
+    for c in range(5):
+        o = sets[c & 1]
+        engine.run_benchmark_async(b2, p2, o[0], o[1], o[2], d_cnt, repack=3)
+    engine.run_benchmark_async(b3, p3, None, o3[0], o3[1], d_cnt, repack=3)      # Greedy first: cannot overlap
+    engine.run_benchmark_async(empty, p2, sets[0][0], sets[0][1], sets[0][2], d_cnt, repack=3)   # nothing to do
+    # the arrays of the last overlapped call may be named again at once: the fall-back calls reset the guard
+    engine.run_benchmark_async(b2, p2, sets[0][0], sets[0][1], sets[0][2], d_cnt, repack=3)
+    engine.synchronize()
+    nw, leap, greedy = oracle.nw(hb2), oracle.leap(hb2, p2.k), oracle.greedy(hb2, p2.k, mode=1)
+    assert np.array_equal(engine.to_host(sets[0][0], n2), nw) and np.array_equal(engine.to_host(sets[0][1], n2), leap)
+    assert np.array_equal(engine.to_host(sets[0][2], n2), greedy) and np.array_equal(engine.to_host(sets[1][2], n2), greedy)
+    assert np.array_equal(engine.to_host(o3[0], n3), oracle.leap(hb3, p3.k))
+    assert np.array_equal(engine.to_host(o3[1], n3), oracle.greedy(hb3, p3.k, mode=1))
+    per = np.array([n2, n2, int((leap == nw).sum()), int((greedy == nw).sum())])
+    assert engine.to_host(d_cnt, 4, np.uint64).tolist() == (6 * per + np.array([n3, 0, 0, 0])).tolist()
+    for x in sets[0] + sets[1] + o3 + [d_cnt]:
+        engine.free(x)
+
+
 def test_profile_events_inside_run_benchmark(asm, engine):
     """asm_profile_enable / asm_profile_read: per-kernel HIP events recorded by the library inside asm_run_benchmark_async
     (what bench.py uses for the dominant kernel's duration inside its timed region)."""
