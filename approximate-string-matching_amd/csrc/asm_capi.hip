@@ -206,7 +206,7 @@ struct asm_batch {
     uint4* d_tails = nullptr;    /* sequential mode: stale-tail planes, uint4[4][n] in input order */
     uint4* d_tail_g0 = nullptr;  /* tail resolver scratch (asm_tails.h), allocated on first use: clean granule 0 in input order, */
     uint32_t* d_tail_l0 = nullptr; /* its lengths, */
-    uint8_t* d_tail_chunks = nullptr; /* per-chunk last writes and carries + the 256-byte summary */
+    uint8_t* d_tail_chunks = nullptr; /* per-chunk prefixes, per-workgroup totals and carries + the 256-byte summary */
     int nb = 1;
     asm_bucket bk[4];
     PackBuckets pb;
@@ -798,29 +798,33 @@ static int batch_resolve_tails(asm_handle* h, asm_batch* b, const uint8_t* init2
     if (summary256) memset(summary256, TAIL_NONE, 256);
     if (b->n == 0) return ASM_OK;
     const long nchunks = (b->n + TAIL_CHUNK - 1) / TAIL_CHUNK;
+    const long ngroups = (nchunks + TAIL_GROUP - 1) / TAIL_GROUP;
     TailState init;
     if (init256) memcpy(init.code, init256, 256);
     else memset(init.code, 0, 256);
     /* scratch lives with the batch: a streamed file re-resolves every chunk, a bench step every iteration */
     if (emit && !b->d_tails) HIPCHK(h, pool_alloc(h, (void**)&b->d_tails, sizeof(uint4) * 4 * (size_t)b->n));
+    const size_t loc_bytes = (size_t)ngroups * TAIL_GROUP * 2 * sizeof(TailOp), grp_bytes = (size_t)ngroups * 2 * sizeof(TailOp);
+    const size_t carry_bytes = (size_t)ngroups * 2 * 2 * sizeof(uint4);
     if (!b->d_tail_g0) {
         HIPCHK(h, pool_alloc(h, (void**)&b->d_tail_g0, sizeof(uint4) * 4 * (size_t)b->n));
         HIPCHK(h, pool_alloc(h, (void**)&b->d_tail_l0, sizeof(uint32_t) * (size_t)b->n));
-        HIPCHK(h, pool_alloc(h, (void**)&b->d_tail_chunks, (size_t)nchunks * 512 + 256)); /* last[nchunks][256], carry[nchunks][256], summary[256] */
+        HIPCHK(h, pool_alloc(h, (void**)&b->d_tail_chunks, loc_bytes + grp_bytes + carry_bytes + 256)); /* loc, grp, gcarry, summary[256] */
     }
-    uint8_t* const d_last = b->d_tail_chunks;
-    uint8_t* const d_carry = d_last + (size_t)nchunks * 256;
-    uint8_t* const d_sum = d_carry + (size_t)nchunks * 256;
+    TailOp* const d_loc = (TailOp*)b->d_tail_chunks;
+    TailOp* const d_grp = (TailOp*)(b->d_tail_chunks + loc_bytes);
+    uint4* const d_carry = (uint4*)(b->d_tail_chunks + loc_bytes + grp_bytes);
+    uint8_t* const d_sum = b->d_tail_chunks + loc_bytes + grp_bytes + carry_bytes;
     PackBuckets one{};
     one.nb = 1, one.w4[0] = 1, one.start[0] = 0, one.start[1] = b->n, one.plane_off[0] = 0;
     HIPCHK(h, launch_pack(h, b, nullptr, b->d_tail_g0, b->d_tail_l0, one, nullptr));
-    hipLaunchKernelGGL(tails_chunk_kernel, dim3((unsigned)nchunks), dim3(256), 0, h->stream, b->d_tail_g0, b->d_tail_l0, (long)b->n,
-                       1, d_last);
-    hipLaunchKernelGGL(tails_carry_kernel, dim3(1), dim3(256 * TAIL_CARRY_SEGS), 0, h->stream, d_last, d_carry, nchunks, init,
-                       summary256 ? d_sum : (uint8_t*)nullptr);
+    hipLaunchKernelGGL(tails_chunk_kernel, dim3((unsigned)ngroups), dim3(2 * TAIL_GROUP), 0, h->stream, b->d_tail_g0, b->d_tail_l0,
+                       (long)b->n, d_loc, d_grp);
+    hipLaunchKernelGGL(tails_carry_kernel, dim3(1), dim3(8 * TAIL_CARRY_SEGS), 0, h->stream, (const uint32_t*)d_grp, (uint32_t*)d_carry,
+                       ngroups, init, summary256 ? d_sum : (uint8_t*)nullptr);
     if (emit)
-        hipLaunchKernelGGL(tails_emit_kernel, dim3((unsigned)nchunks), dim3(256), 0, h->stream, b->d_tail_g0, b->d_tail_l0,
-                           (long)b->n, 1, d_carry, b->d_tails);
+        hipLaunchKernelGGL(tails_emit_kernel, dim3((unsigned)ngroups), dim3(2 * TAIL_GROUP), 0, h->stream, b->d_tail_g0, b->d_tail_l0,
+                           (long)b->n, (const TailOp*)d_loc, (const uint4*)d_carry, b->d_tails);
     HIPCHK(h, hipGetLastError());
     if (summary256) {
         HIPCHK(h, hipMemcpyAsync(summary256, d_sum, 256, hipMemcpyDeviceToHost, h->stream));

@@ -49,7 +49,7 @@ typedef unsigned long long g3_u64;
 #endif
 
 #ifndef G3_TMAX
-#define G3_TMAX 64  /* table domain: hurdles + switches < G3_TMAX */
+#define G3_TMAX 32  /* table domain: hurdles + switches < G3_TMAX; beyond it the FP64 path of the same kernel */
 #endif
 #define G3_LENS 129 /* highway lengths 0..128 */
 #define G3_TABLE_ENTRIES (G3_LENS * G3_TMAX)

@@ -5,7 +5,10 @@
 #include "asm_kernels.h"
 
 
-#define G3_THREADS 512 /* one workgroup per CU: 8 waves = 2 per SIMD; LDS = table + 16 B per lane vector per thread */
+#ifndef G3_THREADS
+#define G3_THREADS 512
+#endif
+/* G3_THREADS: one workgroup per CU: 8 waves = 2 per SIMD; LDS = table + 16 B per lane vector per thread */
 
 template <int NT>
 struct G3LdsStore {
@@ -21,9 +24,12 @@ struct G3LdsTable {
 /* costs of the workgroup's slice staged in LDS and written out in one coalesced sweep at the end (when the slice fits and the
  * results go to their own index): a refilling lane's scattered 4-byte store — 2.5 x write amplification at C2, 64-bit address
  * arithmetic inside the half-empty refill block — becomes one ds_write_b32 */
+#ifndef G3_STAGE_ENTRIES
 #define G3_STAGE_ENTRIES 4096
+#endif
+typedef uint16_t g3_stage_t; /* 0xFFFF: "this cost did not fit and went straight to memory" (never at 128 characters in practice) */
 constexpr size_t g3_lds_bytes(int K, int NT) {
-    return (size_t)G3_TABLE_ENTRIES * 8 + (size_t)(2 * K + 1) * NT * 16 + (size_t)G3_STAGE_ENTRIES * 4;
+    return (size_t)G3_TABLE_ENTRIES * 8 + (size_t)(2 * K + 1) * NT * 16 + (size_t)G3_STAGE_ENTRIES * sizeof(g3_stage_t);
 }
 
 __device__ __forceinline__ G3V g3_from_uint4(uint4 q) {
@@ -42,7 +48,7 @@ __global__ __launch_bounds__(NT) void greedy_fast_kernel(const uint4* __restrict
     extern __shared__ uint4 g3_smem[];
     uint2* const tab = reinterpret_cast<uint2*>(g3_smem);
     G3V* const vecs = reinterpret_cast<G3V*>(g3_smem + G3_TABLE_ENTRIES / 2);
-    int32_t* const stage = reinterpret_cast<int32_t*>(vecs + (size_t)NL * NT);
+    g3_stage_t* const stage = reinterpret_cast<g3_stage_t*>(vecs + (size_t)NL * NT);
     for (int i = threadIdx.x; i < G3_TABLE_ENTRIES / 2; i += NT) g3_smem[i] = reinterpret_cast<const uint4*>(table_g)[i];
     __syncthreads();
     const G3LdsTable table{tab};
@@ -112,8 +118,8 @@ __global__ __launch_bounds__(NT) void greedy_fast_kernel(const uint4* __restrict
                     if (cig.on()) cig.step(pair, ncig, s.cur_lane, s.dest_lane, distance); /* the hurdle count (:589) */
                 }
                 if (cig.on()) cig.finish(pair, ncig);
-                if (staged) stage[idx - slice_lo] = s.cost;
-                else out.put(idx, s.cost);
+                if (staged) stage[idx - slice_lo] = (g3_stage_t)(s.cost < 0xFFFF ? s.cost : 0xFFFF);
+                if (!staged || s.cost >= 0xFFFF) out.put(idx, s.cost);
             }
             long got = -1;
             { /* consecutive pairs for the lanes that need one: rank inside the wave + the workgroup's counter */
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(NT) void greedy_fast_kernel(const uint4* __restrict
     }
     if (staged) { /* every wave leaves the loop through its break: the whole workgroup meets here */
         __syncthreads();
-        for (long q = threadIdx.x; q < slice_hi - slice_lo; q += NT) out.out[slice_lo + q] = stage[q];
+        for (long q = threadIdx.x; q < slice_hi - slice_lo; q += NT) if (stage[q] != 0xFFFFu) out.out[slice_lo + q] = (int32_t)stage[q];
     }
 #ifdef GREEDY_DIAG
     if ((threadIdx.x & 63) == 0 && cig.nops != nullptr && cig.ops == nullptr) { /* diag build: cig.nops doubles as the debug buffer */

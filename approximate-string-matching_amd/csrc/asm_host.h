@@ -91,6 +91,54 @@ static inline int tail_slot_after(int slot, long long n) {
     return slot;
 }
 
+// The same step on all 128 slots of a buffer at once, one bit per slot (bit q of w[q >> 5] = slot q): what the resolver's
+// device passes run per pair and plane (csrc/asm_tails.h).  after[q] = before[SRC[q]] reads the buffer as 16 bytes of 8 bits and
+// leaves 8 halfwords of 16 bits: halfword j, bit r = byte r, bit P[j] — two 8x8 bit transposes (bytes 0-7, bytes 8-15), then
+// byte (P[j]) of the first next to byte (P[j]) of the second.  constexpr: clang compiles these for host and device alike, and
+// the static_assert below checks the permutation against its definition for every slot while the library is being compiled.
+struct TailBits {
+    uint32_t w[4];
+};
+constexpr uint32_t tail_bfi(uint32_t m, uint32_t x, uint32_t y) { return (x & m) | (y & ~m); } /* v_bfi_b32 */
+constexpr void tail_transpose8(uint32_t& lo, uint32_t& hi) { /* bytes 0-3 in lo, 4-7 in hi: byte c, bit r <- byte r, bit c */
+    lo = tail_bfi(0xAA55AA55u, lo, tail_bfi(0x00AA00AAu, lo >> 7, lo << 7));
+    hi = tail_bfi(0xAA55AA55u, hi, tail_bfi(0x00AA00AAu, hi >> 7, hi << 7));
+    lo = tail_bfi(0xCCCC3333u, lo, tail_bfi(0x0000CCCCu, lo >> 14, lo << 14));
+    hi = tail_bfi(0xCCCC3333u, hi, tail_bfi(0x0000CCCCu, hi >> 14, hi << 14));
+    const uint32_t l2 = tail_bfi(0x0F0F0F0Fu, lo, hi << 4);
+    hi = tail_bfi(0xF0F0F0F0u, hi, lo >> 4);
+    lo = l2;
+}
+constexpr TailBits tail_permute(TailBits v) {
+    uint32_t a0 = v.w[0], a1 = v.w[1], b0 = v.w[2], b1 = v.w[3];
+    tail_transpose8(a0, a1);
+    tail_transpose8(b0, b1);
+    TailBits o{};
+    o.w[0] = tail_bfi(0x00FF00FFu, a0, b0 << 8);      /* halfwords 0, 1: bytes P[0] = 0 and P[1] = 2 of both transposes */
+    o.w[1] = tail_bfi(0x00FF00FFu, a0 >> 8, b0);      /* halfwords 2, 3: bytes 1, 3 */
+    o.w[2] = tail_bfi(0x00FF00FFu, a1, b1 << 8);      /* halfwords 4, 5: bytes 4, 6 */
+    o.w[3] = tail_bfi(0x00FF00FFu, a1 >> 8, b1);      /* halfwords 6, 7: bytes 5, 7 */
+    return o;
+}
+constexpr uint32_t tail_prefix_word(uint32_t len, uint32_t lo) { /* the bits of [0, len) that fall into slots [lo, lo + 32) */
+    return len >= lo + 32u ? 0xFFFFFFFFu : (len > lo ? (1u << ((len - lo) & 31u)) - 1u : 0u);
+}
+constexpr TailBits tail_prefix(uint32_t len) { /* slots [0, len), len <= 128 */
+    return TailBits{{tail_prefix_word(len, 0u), tail_prefix_word(len, 32u), tail_prefix_word(len, 64u), tail_prefix_word(len, 96u)}};
+}
+constexpr bool tail_permute_selfcheck() {
+    for (int q = 0; q < 128; q++) { /* a byte in slot s moves to tail_slot_after(s, 1) */
+        TailBits one{};
+        one.w[q >> 5] = 1u << (q & 31);
+        const TailBits got = tail_permute(one);
+        const int v = q & 7, low2 = v & 3, pv = (low2 == 1 || low2 == 2) ? (v ^ 3) : v, to = (pv << 4) | (q >> 3);
+        for (int d = 0; d < 4; d++)
+            if (got.w[d] != ((to >> 5) == d ? 1u << (to & 31) : 0u)) return false;
+    }
+    return true;
+}
+static_assert(tail_permute_selfcheck(), "tail_permute does not move slot s to SRC^-1[s]");
+
 inline int tail_state_advance(uint8_t* state, const uint8_t* summary, int64_t n_pairs, std::string& err) {
     if (!state || !summary || n_pairs < 0) return err = "asm_tail_state_advance: bad argument", ASM_EINVAL;
     uint8_t next[256];

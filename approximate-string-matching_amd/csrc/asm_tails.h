@@ -5,16 +5,19 @@
 // (GASMA/bit_convert.cpp:265-330: after[q] = before[SRC[q]], SRC[q] = 8*(q mod 16) + P[q div 16], P = {0,2,1,3,4,6,5,7}).
 // So the bytes beyond a string's end that the conversion of pair t sees are scrambled characters of earlier pairs.
 //
-// Parallel formulation.  Follow one buffer slot forward in time: a byte sitting in slot s when pair t is converted
-// sits in slot SRC^-1[s] when pair t+1 is converted — unless pair t+1's string is long enough to overwrite it.  So
-// each of the 128 slots of a side starts a *trajectory* s, SRC^-1[s], SRC^-1[SRC^-1[s]], ... that carries "the code
-// of the last character written on this trajectory".  SRC has order 10 (cycles of length 1, 2, 5, 10), so after any
-// multiple of 10 pairs every trajectory is back in its starting slot; with chunks of 640 pairs the trajectories of
-// consecutive chunks line up by thread index and the carried state is just a 2-bit code:
-//   pass 1  tails_chunk_kernel : per chunk and trajectory, the code of the last write inside the chunk (or none)
-//   pass 2  tails_carry_kernel : exclusive "last write wins" prefix over chunks (initial buffers = NUL, code 00)
-//   pass 3  tails_emit_kernel  : replay each chunk from its carry-in; wherever the trajectory's slot lies beyond the
-//                                pair's string, that pair's conversion sees the carried code: set the bits in `tails`
+// Parallel formulation (round 4: bit-parallel; rounds 2-3 walked one trajectory per thread and set the tail bits with LDS
+// atomics, 0.78 ms per 10^6 pairs in the three kernels).  A buffer's state is two 128-bit planes S0, S1: bit q of Sp = bit p
+// of the 2-bit code of the character sitting in slot q.  Pair t with (clamped) length L and clean-mode planes A0, A1:
+//     tails_t = S & ~[0, L)                  what the conversion of pair t sees beyond the string
+//     S      <- permute((A & [0, L)) | (S & ~[0, L)))       the copy, then the in-place permutation
+// and `permute` is a 16 x 8 bit-matrix transpose (asm_host.h: tail_permute, ~44 integer instructions per plane).  One thread
+// owns a whole buffer for a chunk of consecutive pairs; three passes make the chunks independent:
+//   pass 1  tails_chunk_kernel : per chunk, its effect on the buffer from an unknown start: W = slots written, C = their codes;
+//                                then an exclusive scan of (W, C) over the workgroup's 128 chunks in LDS
+//   pass 2  tails_carry_kernel : the same scan over the workgroups' totals (one workgroup; initial buffers from `init`)
+//   pass 3  tails_emit_kernel  : replay each chunk from its carry-in, writing tails_t
+// SRC has order 10, so with chunks of a multiple of 10 pairs the permutations inside a chunk compose to the identity and two
+// chunks' effects compose slot by slot: "the later write wins", (W2, C2) o (W1, C1) = (W1 | W2, C2 where W2 else C1).
 // Character codes are read from the clean-mode bit planes (bit q of a plane <-> character q), so the passes touch no
 // ASCII.  The pack kernel ORs `tails` into granule 0.  Initial buffer content is pinned to zero (the reference's is
 // indeterminate heap memory).
@@ -22,82 +25,108 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "asm_host.h" /* TAIL_NONE, tail_slot_after: the host side of the chain */
+#include "asm_host.h" /* TAIL_NONE, TailBits, tail_permute, tail_prefix: shared with the host side of the chain */
 
-#define TAIL_CHUNK 640  /* pairs per chunk: a multiple of 10 (the order of SRC); 10^6 pairs = 1563 workgroups, one round of the chip */
-#define TAIL_SUB 256    /* pairs whose tail planes are accumulated in LDS at a time */
-#define TAIL_BATCH 16   /* pairs whose plane words are fetched ahead (the walk is a chain of dependent round trips to HBM) */
+#define TAIL_CHUNK 40   /* pairs per chunk: a multiple of 10 (the order of SRC); 10^6 pairs = 50 000 threads per pass */
+#define TAIL_GROUP 128  /* chunks per workgroup: thread = (side, chunk) */
+#define TAIL_AHEAD 4    /* pairs whose lengths and planes are fetched before the first of them is walked */
 
-// SRC^-1: SRC[q] = 8*(q & 15) + P[q >> 4] and P is an involution, so q = (P[y & 7] << 4) | (y >> 3).
-__device__ __forceinline__ int tail_src_inv(int y) {
-    const int v = y & 7;
-    const int low2 = v & 3;
-    const int pv = (low2 == 1 || low2 == 2) ? (v ^ 3) : v; /* P swaps 1<->2 and 5<->6 */
-    return (pv << 4) | (y >> 3);
-}
+using asm_host::TailBits;
 
-struct TailLane {
-    int side, slot;
-    const uint32_t *p0, *p1; /* this side's two bit planes, granule 0, viewed as dwords (4 per pair) */
+struct TailOp { /* the effect of a run of pairs on one buffer, in the slot frame of the run's first pair */
+    TailBits w, c0, c1;
 };
 
-__device__ __forceinline__ TailLane tail_lane_init(const uint4* planes, long n, int w4) {
-    TailLane tl;
-    tl.side = threadIdx.x >> 7;
-    tl.slot = threadIdx.x & 127;
-    tl.p0 = reinterpret_cast<const uint32_t*>(planes + ((long)(2 * tl.side) * w4) * n);
-    tl.p1 = reinterpret_cast<const uint32_t*>(planes + ((long)(2 * tl.side + 1) * w4) * n);
-    return tl;
+__device__ __forceinline__ TailBits tail_select(TailBits m, TailBits x, TailBits y) { /* x where m, else y */
+    TailBits o;
+#pragma unroll
+    for (int d = 0; d < 4; d++) o.w[d] = asm_host::tail_bfi(m.w[d], x.w[d], y.w[d]);
+    return o;
+}
+__device__ __forceinline__ TailBits tail_from(uint4 v) { return TailBits{{v.x, v.y, v.z, v.w}}; }
+__device__ __forceinline__ uint4 tail_to(TailBits b) { return make_uint4(b.w[0], b.w[1], b.w[2], b.w[3]); }
+__device__ __forceinline__ TailOp tail_then(const TailOp& first, const TailOp& later) {
+    TailOp o;
+#pragma unroll
+    for (int d = 0; d < 4; d++) o.w.w[d] = first.w.w[d] | later.w.w[d];
+    o.c0 = tail_select(later.w, later.c0, first.c0);
+    o.c1 = tail_select(later.w, later.c1, first.c1);
+    return o;
 }
 
-// One batch of up to TAIL_BATCH pairs starting at t: all loads first (the slot sequence is data independent), then
-// the sequential replay.  EMIT=false: only track the carried code.  EMIT=true: also set tail bits in LDS.
-template <bool EMIT>
-__device__ __forceinline__ void tail_batch(TailLane& tl, const uint32_t* __restrict__ lens, long t, int cnt,
-                                           uint32_t& code, uint32_t* s_tail, long sub_base) {
-    int slots[TAIL_BATCH];
-    uint32_t L[TAIL_BATCH], w0[TAIL_BATCH], w1[TAIL_BATCH];
-    int s = tl.slot;
-#pragma unroll
-    for (int i = 0; i < TAIL_BATCH; i++) {
-        slots[i] = s;
-        s = tail_src_inv(s);
-        const long tt = t + (i < cnt ? i : cnt - 1);
-        const uint32_t ln = lens[tt];
-        uint32_t len = tl.side ? (ln >> 16) : (ln & 0xffffu);
-        L[i] = len > 128u ? 128u : len; /* hurdle_matrix.h:626-627 */
-        w0[i] = tl.p0[tt * 4 + (slots[i] >> 5)];
-        w1[i] = tl.p1[tt * 4 + (slots[i] >> 5)];
+// One pair's step on one buffer: emit what the conversion sees beyond the string, copy the string in, permute.
+template <bool TRACK_W, bool EMIT>
+__device__ __forceinline__ void tail_step(uint32_t len2, uint4 a0, uint4 a1, int shift, TailBits& s0, TailBits& s1, TailBits& w,
+                                          uint4* __restrict__ out0, uint4* __restrict__ out1) {
+    uint32_t L = (len2 >> shift) & 0xffffu;
+    L = L > 128u ? 128u : L; /* hurdle_matrix.h:626-627 */
+    const TailBits m = asm_host::tail_prefix(L);
+    if (EMIT) {
+        const TailBits zero{{0u, 0u, 0u, 0u}};
+        *out0 = tail_to(tail_select(m, zero, s0));
+        *out1 = tail_to(tail_select(m, zero, s1));
     }
-#pragma unroll
-    for (int i = 0; i < TAIL_BATCH; i++) {
-        if (i < cnt) {
-            const int q = slots[i];
-            if ((uint32_t)q < L[i]) {
-                code = ((w0[i] >> (q & 31)) & 1u) | (((w1[i] >> (q & 31)) & 1u) << 1); /* this pair overwrites the slot */
-            } else if (EMIT && code != 0u) {
-                /* slot q lies beyond pair (t+i)'s string: its conversion sees the carried character */
-                uint32_t* row = s_tail + ((size_t)(t + i - sub_base) * 4 + 2 * tl.side) * 4;
-                if (code & 1u) atomicOr(&row[q >> 5], 1u << (q & 31));
-                if (code & 2u) atomicOr(&row[4 + (q >> 5)], 1u << (q & 31));
-            }
-            tl.slot = tail_src_inv(q);
-        }
+    s0 = asm_host::tail_permute(tail_select(m, tail_from(a0), s0));
+    s1 = asm_host::tail_permute(tail_select(m, tail_from(a1), s1));
+    if (TRACK_W) {
+        w.w[0] |= m.w[0], w.w[1] |= m.w[1], w.w[2] |= m.w[2], w.w[3] |= m.w[3];
+        w = asm_host::tail_permute(w);
     }
 }
 
-__global__ __launch_bounds__(256) void tails_chunk_kernel(const uint4* __restrict__ planes,
-                                                          const uint32_t* __restrict__ lens, long n, int w4,
-                                                          uint8_t* __restrict__ chunk_last /* [nchunks][256] */) {
-    TailLane tl = tail_lane_init(planes, n, w4);
-    const long t0 = (long)blockIdx.x * TAIL_CHUNK;
-    const long t1 = t0 + TAIL_CHUNK < n ? t0 + TAIL_CHUNK : n;
-    uint32_t code = TAIL_NONE;
-    for (long t = t0; t < t1; t += TAIL_BATCH) {
-        const int cnt = (t1 - t) < TAIL_BATCH ? (int)(t1 - t) : TAIL_BATCH;
-        tail_batch<false>(tl, lens, t, cnt, code, nullptr, 0);
+// The walk of one buffer over pairs [t0, t0 + cnt) (cnt <= TAIL_CHUNK).  TRACK_W: also collect the written slots (pass 1).
+// EMIT: write tails_t (pass 3).  TAIL_AHEAD pairs are fetched before the first of them is walked (the fetches do not depend on
+// the state); the pairs left over, and the cnt mod 10 permutations that bring pass 1's planes back into the slot frame of the
+// chunk's first pair, are only ever the batch's last chunk's.
+template <bool TRACK_W, bool EMIT>
+__device__ __forceinline__ void tail_walk(const uint4* __restrict__ planes, const uint32_t* __restrict__ lens, long n, int side,
+                                          long t0, int cnt, TailBits& s0, TailBits& s1, TailBits& w, uint4* __restrict__ tails) {
+    const uint4* __restrict__ p0 = planes + (long)(2 * side) * n + t0;
+    const uint4* __restrict__ p1 = planes + (long)(2 * side + 1) * n + t0;
+    const uint32_t* __restrict__ pl = lens + t0;
+    uint4* __restrict__ o0 = tails + (EMIT ? (long)(2 * side) * n + t0 : 0);
+    uint4* __restrict__ o1 = tails + (EMIT ? (long)(2 * side + 1) * n + t0 : 0);
+    const int shift = side ? 16 : 0;
+    int i = 0;
+    for (; i + TAIL_AHEAD <= cnt; i += TAIL_AHEAD) {
+        uint32_t ln[TAIL_AHEAD];
+        uint4 a0[TAIL_AHEAD], a1[TAIL_AHEAD];
+#pragma unroll
+        for (int j = 0; j < TAIL_AHEAD; j++) ln[j] = pl[i + j], a0[j] = p0[i + j], a1[j] = p1[i + j];
+#pragma unroll
+        for (int j = 0; j < TAIL_AHEAD; j++) tail_step<TRACK_W, EMIT>(ln[j], a0[j], a1[j], shift, s0, s1, w, o0 + i + j, o1 + i + j);
     }
-    chunk_last[(long)blockIdx.x * 256 + threadIdx.x] = (uint8_t)code;
+    for (; i < cnt; i++) tail_step<TRACK_W, EMIT>(pl[i], p0[i], p1[i], shift, s0, s1, w, o0 + i, o1 + i);
+    for (int r = cnt % 10; !EMIT && r != 0 && r < 10; r++) {
+        s0 = asm_host::tail_permute(s0), s1 = asm_host::tail_permute(s1);
+        if (TRACK_W) w = asm_host::tail_permute(w);
+    }
+}
+
+// Scratch layout (asm_capi.hip: batch_resolve_tails): loc[nchunks_padded][2] = a chunk's exclusive prefix inside its workgroup,
+// grp[ngroups][2] = a workgroup's total, gcarry[ngroups][2][2] = the buffers' planes S0, S1 before a workgroup's first pair.
+__global__ __launch_bounds__(2 * TAIL_GROUP) void tails_chunk_kernel(const uint4* __restrict__ planes,
+                                                                     const uint32_t* __restrict__ lens, long n,
+                                                                     TailOp* __restrict__ loc, TailOp* __restrict__ grp) {
+    __shared__ TailOp s_op[2][TAIL_GROUP + 1]; /* [0] = "nothing written", chunk ci at [ci + 1] */
+    const int side = threadIdx.x / TAIL_GROUP, ci = threadIdx.x % TAIL_GROUP;
+    const long chunk = (long)blockIdx.x * TAIL_GROUP + ci;
+    const long t0 = chunk * TAIL_CHUNK;
+    const int cnt = t0 >= n ? 0 : (int)((t0 + TAIL_CHUNK < n ? t0 + TAIL_CHUNK : n) - t0);
+    TailOp mine{};
+    if (ci == 0) s_op[side][0] = mine;
+    if (cnt > 0) tail_walk<true, false>(planes, lens, n, side, t0, cnt, mine.c0, mine.c1, mine.w, nullptr);
+    /* (the walk started from zero planes: C is zero wherever W is not) */
+    s_op[side][ci + 1] = mine;
+    __syncthreads();
+    for (int off = 1; off < TAIL_GROUP; off <<= 1) { /* inclusive scan over the workgroup's chunks, per side */
+        const TailOp prev = s_op[side][ci >= off ? ci + 1 - off : 0];
+        __syncthreads();
+        mine = tail_then(prev, mine), s_op[side][ci + 1] = mine;
+        __syncthreads();
+    }
+    loc[chunk * 2 + side] = s_op[side][ci];
+    if (ci == TAIL_GROUP - 1) grp[(long)blockIdx.x * 2 + side] = mine;
 }
 
 // `init` ([256] = [side][slot]): the codes the two buffers hold before the first pair of this batch — zeros (NUL
@@ -107,79 +136,78 @@ __global__ __launch_bounds__(256) void tails_chunk_kernel(const uint4* __restric
 struct TailState { /* passed by value: no host buffer has to outlive the enqueue */
     uint8_t code[256];
 };
-// `init` ([256] = [side][slot]): the codes the two buffers hold before the first pair of this batch — zeros (NUL
-// bytes) for a batch that starts a file, the state after the previous shard/chunk otherwise (asm_tail_state_advance).
-// `summary` (optional, [256]): per trajectory, indexed by its slot before the first pair, the code of the last character the
-// batch wrote on it, or TAIL_NONE when the batch never touched it — the batch's whole effect on the buffers.
-// One workgroup of 1024 threads = 256 trajectories x 4 segments of the chunk sequence: every thread first finds the last
-// write inside its segment, the four meet in LDS, then every thread replays its segment from the right carry-in — two walks of
-// nchunks / 4 entries with 16 independent loads in flight, instead of one dependent walk over all chunks.
-#define TAIL_CARRY_SEGS 4
-__global__ __launch_bounds__(256 * TAIL_CARRY_SEGS) void tails_carry_kernel(const uint8_t* __restrict__ chunk_last,
-                                                                            uint8_t* __restrict__ carry_in, long nchunks,
-                                                                            TailState init, uint8_t* __restrict__ summary) {
-    __shared__ uint8_t s_seg[TAIL_CARRY_SEGS][256];
-    const int tr = threadIdx.x & 255, seg = threadIdx.x >> 8;
-    const long per = (nchunks + TAIL_CARRY_SEGS - 1) / TAIL_CARRY_SEGS;
-    const long c0 = seg * per, c1 = c0 + per < nchunks ? c0 + per : nchunks;
-    uint32_t last = TAIL_NONE;
-    for (long c = c0; c < c1; c += 16) {
-        uint32_t v[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++) v[q] = c + q < c1 ? chunk_last[(c + q) * 256 + tr] : TAIL_NONE;
-#pragma unroll
-        for (int q = 0; q < 16; q++)
-            if (v[q] != TAIL_NONE) last = v[q];
-    }
-    s_seg[seg][tr] = (uint8_t)last;
-    __syncthreads();
-    uint32_t cur = (uint32_t)init.code[tr]; /* a file starts with NUL bytes: code 00 */
-    for (int q = 0; q < seg; q++)
-        if (s_seg[q][tr] != TAIL_NONE) cur = s_seg[q][tr];
-    for (long c = c0; c < c1; c += 16) {
-        uint32_t v[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++) v[q] = c + q < c1 ? chunk_last[(c + q) * 256 + tr] : TAIL_NONE;
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            if (c + q < c1) carry_in[(c + q) * 256 + tr] = (uint8_t)cur;
-            if (v[q] != TAIL_NONE) cur = v[q];
+// One workgroup: thread = (segment of the workgroup sequence, side, dword of the planes) — the scan is bitwise, so the eight
+// (side, dword) columns are independent.  Every thread folds its segment, the segments meet in LDS, then every thread replays
+// its segment from the right carry-in.
+#define TAIL_CARRY_SEGS 32
+__global__ __launch_bounds__(8 * TAIL_CARRY_SEGS) void tails_carry_kernel(const uint32_t* __restrict__ grp /* TailOp[ngroups][2] */,
+                                                                          uint32_t* __restrict__ gcarry /* [ngroups][2][2][4] */,
+                                                                          long ngroups, TailState init, uint8_t* __restrict__ summary) {
+    __shared__ uint32_t s_seg[TAIL_CARRY_SEGS][8][3];
+    __shared__ uint32_t s_init[2][2][4], s_tot[2][3][4];
+    {   /* the initial buffers as planes: wave v holds slots 64 * (v & 1) .. of side v >> 1 */
+        const uint32_t code = init.code[threadIdx.x];
+        const unsigned long long b0 = __ballot(code & 1u), b1 = __ballot(code & 2u);
+        if ((threadIdx.x & 63) == 0) {
+            const int sd = threadIdx.x >> 7, half = (threadIdx.x >> 6) & 1;
+            s_init[sd][0][2 * half] = (uint32_t)b0, s_init[sd][0][2 * half + 1] = (uint32_t)(b0 >> 32);
+            s_init[sd][1][2 * half] = (uint32_t)b1, s_init[sd][1][2 * half + 1] = (uint32_t)(b1 >> 32);
         }
     }
-    if (summary && seg == TAIL_CARRY_SEGS - 1) {
-        uint32_t all = TAIL_NONE;
-        for (int q = 0; q < TAIL_CARRY_SEGS; q++)
-            if (s_seg[q][tr] != TAIL_NONE) all = s_seg[q][tr];
-        summary[tr] = (uint8_t)all;
+    const int col = threadIdx.x & 7, seg = threadIdx.x >> 3; /* col = side * 4 + dword */
+    const int side = col >> 2, d = col & 3;
+    const long per = (ngroups + TAIL_CARRY_SEGS - 1) / TAIL_CARRY_SEGS;
+    const long g0 = seg * per, g1 = g0 + per < ngroups ? g0 + per : ngroups;
+    uint32_t w = 0u, c0 = 0u, c1 = 0u;
+    for (long g = g0; g < g1; g++) {
+        const uint32_t* op = grp + (g * 2 + side) * 12;
+        const uint32_t gw = op[d];
+        w |= gw, c0 = asm_host::tail_bfi(gw, op[4 + d], c0), c1 = asm_host::tail_bfi(gw, op[8 + d], c1);
+    }
+    s_seg[seg][col][0] = w, s_seg[seg][col][1] = c0, s_seg[seg][col][2] = c1;
+    __syncthreads();
+    uint32_t cur0 = s_init[side][0][d], cur1 = s_init[side][1][d];
+    for (int q = 0; q < seg; q++) {
+        const uint32_t gw = s_seg[q][col][0];
+        cur0 = asm_host::tail_bfi(gw, s_seg[q][col][1], cur0), cur1 = asm_host::tail_bfi(gw, s_seg[q][col][2], cur1);
+    }
+    for (long g = g0; g < g1; g++) {
+        uint32_t* out = gcarry + (g * 2 + side) * 8;
+        out[d] = cur0, out[4 + d] = cur1;
+        const uint32_t* op = grp + (g * 2 + side) * 12;
+        const uint32_t gw = op[d];
+        cur0 = asm_host::tail_bfi(gw, op[4 + d], cur0), cur1 = asm_host::tail_bfi(gw, op[8 + d], cur1);
+    }
+    if (summary) {
+        if (seg == 0) {
+            uint32_t tw = 0u, t0 = 0u, t1 = 0u;
+            for (int q = 0; q < TAIL_CARRY_SEGS; q++) {
+                const uint32_t gw = s_seg[q][col][0];
+                tw |= gw, t0 = asm_host::tail_bfi(gw, s_seg[q][col][1], t0), t1 = asm_host::tail_bfi(gw, s_seg[q][col][2], t1);
+            }
+            s_tot[side][0][d] = tw, s_tot[side][1][d] = t0, s_tot[side][2][d] = t1;
+        }
+        __syncthreads();
+        const int sd = threadIdx.x >> 7, slot = threadIdx.x & 127;
+        const uint32_t bit = 1u << (slot & 31);
+        const uint32_t code = ((s_tot[sd][1][slot >> 5] & bit) ? 1u : 0u) | ((s_tot[sd][2][slot >> 5] & bit) ? 2u : 0u);
+        summary[threadIdx.x] = (uint8_t)((s_tot[sd][0][slot >> 5] & bit) ? code : TAIL_NONE);
     }
 }
 
-__global__ __launch_bounds__(256) void tails_emit_kernel(const uint4* __restrict__ planes,
-                                                         const uint32_t* __restrict__ lens, long n, int w4,
-                                                         const uint8_t* __restrict__ carry_in,
-                                                         uint4* __restrict__ tails /* [4][n] */) {
-    __shared__ uint32_t s_tail[TAIL_SUB * 16]; /* [pair][plane A0,A1,B0,B1][4 dwords] */
-    TailLane tl = tail_lane_init(planes, n, w4);
-    const long t0 = (long)blockIdx.x * TAIL_CHUNK;
-    const long t1 = t0 + TAIL_CHUNK < n ? t0 + TAIL_CHUNK : n;
-    uint32_t code = carry_in[(long)blockIdx.x * 256 + threadIdx.x];
-    for (long sb = t0; sb < t1; sb += TAIL_SUB) {
-        const long se = sb + TAIL_SUB < t1 ? sb + TAIL_SUB : t1;
-        for (int i = threadIdx.x; i < TAIL_SUB * 16; i += 256) s_tail[i] = 0u;
-        __syncthreads();
-        for (long t = sb; t < se; t += TAIL_BATCH) {
-            const int cnt = (se - t) < TAIL_BATCH ? (int)(se - t) : TAIL_BATCH;
-            tail_batch<true>(tl, lens, t, cnt, code, s_tail, sb);
-        }
-        __syncthreads();
-        // flush: thread i owns pair sb+i
-        const long t = sb + threadIdx.x;
-        if (t < se) {
-            const uint32_t* row = s_tail + (size_t)threadIdx.x * 16;
-#pragma unroll
-            for (int p = 0; p < 4; p++)
-                tails[(long)p * n + t] = make_uint4(row[4 * p], row[4 * p + 1], row[4 * p + 2], row[4 * p + 3]);
-        }
-        __syncthreads();
-    }
+__global__ __launch_bounds__(2 * TAIL_GROUP) void tails_emit_kernel(const uint4* __restrict__ planes,
+                                                                    const uint32_t* __restrict__ lens, long n,
+                                                                    const TailOp* __restrict__ loc,
+                                                                    const uint4* __restrict__ gcarry /* [ngroups][2][2] */,
+                                                                    uint4* __restrict__ tails /* [4][n] */) {
+    const int side = threadIdx.x / TAIL_GROUP, ci = threadIdx.x % TAIL_GROUP;
+    const long chunk = (long)blockIdx.x * TAIL_GROUP + ci;
+    const long t0 = chunk * TAIL_CHUNK;
+    if (t0 >= n) return;
+    const int cnt = (int)((t0 + TAIL_CHUNK < n ? t0 + TAIL_CHUNK : n) - t0);
+    const TailOp before = loc[chunk * 2 + side];
+    TailBits s0 = tail_select(before.w, before.c0, tail_from(gcarry[((long)blockIdx.x * 2 + side) * 2]));
+    TailBits s1 = tail_select(before.w, before.c1, tail_from(gcarry[((long)blockIdx.x * 2 + side) * 2 + 1]));
+    TailBits unused{};
+    tail_walk<false, true>(planes, lens, n, side, t0, cnt, s0, s1, unused, tails);
 }

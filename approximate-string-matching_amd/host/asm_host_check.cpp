@@ -174,6 +174,40 @@ int main(int argc, char** argv) {
         EXPECT(tail_state_advance(st2, sum, 1, err) == ASM_EINVAL, "summary entry 17 accepted");
         EXPECT(tail_state_advance(nullptr, sum, 1, err) == ASM_EINVAL, "NULL state accepted");
     }
+    {   /* the resolver's bit-plane step (tail_permute, tail_prefix: what csrc/asm_tails.h runs per pair) against the byte buffer
+           it stands for: copy the first L codes in, then after[q] = before[8 * (q & 15) + P[q >> 4]] (bit_convert.cpp:265-330) */
+        static const int P[8] = {0, 2, 1, 3, 4, 6, 5, 7};
+        uint8_t buf[128] = {0};
+        TailBits s0{}, s1{};
+        uint64_t rng = 88172645463325252ull;
+        auto next = [&rng] { return rng ^= rng << 13, rng ^= rng >> 7, rng ^= rng << 17, (uint32_t)(rng >> 11); };
+        int bad = 0;
+        for (int t = 0; t < 2000 && !bad; t++) {
+            const uint32_t L = t % 7 == 0 ? (t % 14 ? 128u : 0u) : next() % 129u;
+            TailBits a0{}, a1{};
+            for (uint32_t q = 0; q < L; q++) {
+                const uint8_t code = (uint8_t)(next() & 3u);
+                buf[q] = code;
+                a0.w[q >> 5] |= (uint32_t)(code & 1u) << (q & 31), a1.w[q >> 5] |= (uint32_t)(code >> 1) << (q & 31);
+            }
+            const TailBits m = tail_prefix(L);
+            for (uint32_t q = 0; q < 128; q++) { /* what the conversion sees: the string, then the stale codes */
+                const uint32_t want = buf[q], bit = 1u << (q & 31);
+                const uint32_t t0 = q < L ? a0.w[q >> 5] : (s0.w[q >> 5] & ~m.w[q >> 5]), t1 = q < L ? a1.w[q >> 5] : (s1.w[q >> 5] & ~m.w[q >> 5]);
+                if ((((t0 & bit) ? 1u : 0u) | ((t1 & bit) ? 2u : 0u)) != want) bad++;
+            }
+            uint8_t after[128];
+            for (int q = 0; q < 128; q++) after[q] = buf[8 * (q & 15) + P[q >> 4]];
+            memcpy(buf, after, 128);
+            TailBits n0{}, n1{};
+            for (int d = 0; d < 4; d++) n0.w[d] = tail_bfi(m.w[d], a0.w[d], s0.w[d]), n1.w[d] = tail_bfi(m.w[d], a1.w[d], s1.w[d]);
+            s0 = tail_permute(n0), s1 = tail_permute(n1);
+        }
+        EXPECT(bad == 0, "bit-plane buffer step differs from the byte buffer");
+        TailBits x{{0x12345678u, 0x9abcdef0u, 0x0fedcba9u, 0x87654321u}}, y = x;
+        for (int r = 0; r < 10; r++) y = tail_permute(y);
+        EXPECT(memcmp(&x, &y, sizeof x) == 0, "tail_permute does not have order 10");
+    }
     {   /* CIGAR rows: formatting, truncated rows, output buffers of every size down to one byte */
         const uint16_t ops[5] = {(uint16_t)(22 << 3 | 0), (uint16_t)(1 << 3 | 2), (uint16_t)(50 << 3 | 0), (uint16_t)(1 << 3 | 1), (uint16_t)(128 << 3 | 4)};
         char out[64];
