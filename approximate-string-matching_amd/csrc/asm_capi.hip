@@ -1887,10 +1887,10 @@ int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, in
         h->last3_out[0] = d_nw, h->last3_out[1] = d_leap, h->last3_out[2] = d_greedy;
         h->last3_valid = true;
         /* OVERLAPPED calls: nothing of this call waits for the previous call's Greedy, and the caller's stream is not joined
-         * here (asm_pipeline_join_async does that).  Three chains run through consecutive calls — NW -> LEAP -> NW -> ... on the
-         * caller's stream, Greedy -> Greedy on the side stream, pack -> pack on the pack stream — and each call's counters
-         * run behind its two aligner chains on a fourth stream, whose event also frees the call's plane set for the pack two
-         * calls later (and, with the caller alternating output arrays, says those arrays may be written again). */
+         * here (asm_pipeline_join_async does that).  Three chains run through consecutive calls — NW -> LEAP -> counters -> NW
+         * -> ... on a stream of the library, Greedy -> Greedy on the side stream, pack -> pack on the pack stream; a call's
+         * counters wait for its Greedy, and their event also frees the call's plane set for the pack two calls later (and, with
+         * the caller alternating output arrays, says those arrays may be written again). */
         /* the output arrays were last written two calls ago (the caller alternates): behind that call's counters.  For calls
          * on ONE batch ev_packed already implies it; calls on different batches have nothing else that orders them. */
         hipEvent_t out_free = h->ev_out[h->calls3 & 1u];
@@ -1911,19 +1911,26 @@ int asm_run_benchmark_async(asm_handle* h, asm_batch* b, const asm_params* p, in
             PROF(3, 1, side)
             if (!rc) HIPCHK(h, hipEventRecord(h->ev_join, side));
         }
+        /* NW -> LEAP -> counters of a call, then the next call's NW, in a row on ONE stream (when all three are asked for).
+         * Rounds 3-4 launched NW on the caller's stream and LEAP + counters on a stream of the library; under torch the two
+         * shared a hardware queue (the runtime spreads streams over four, the handle's idle own stream holds one), which
+         * serialised them in exactly this order — and that order is the fast one: with GPU_MAX_HW_QUEUES=8, where the next NW
+         * really starts beside this call's LEAP and counters, a step takes 0.219 ms against 0.204.  Saying so explicitly makes
+         * the step independent of how the host's streams happen to map to queues (same box: 0.206 at four queues, 0.208 at
+         * eight). */
+        hipStream_t chain = (d_nw && d_leap) ? h->acc_stream : main_stream;
+        if (chain != main_stream) HIPCHK(h, hipStreamWaitEvent(chain, h->ev_packed, 0));
         if (!rc && d_nw) {
-            PROF(1, 0, main_stream)
+            PROF(1, 0, chain)
+            h->stream = chain;
             rc = asm_align_batch_async(h, b, ASM_NW, p, d_nw);
-            PROF(1, 1, main_stream)
+            h->stream = main_stream;
+            PROF(1, 1, chain)
         }
-        /* LEAP on the counters' stream when there is an NW to wait for: the next call's NW then follows this call's NW directly,
-         * and the chain on that stream is LEAP -> counters -> LEAP.  (The HIP runtime spreads streams over four hardware queues:
-         * a fifth busy stream shares a queue with another and serialises with it — measured 0.26-0.29 ms per step —, so LEAP
-         * gets no stream of its own.) */
         hipStream_t ls = (d_nw && d_leap) ? h->acc_stream : main_stream;
         if (!rc && d_leap) {
-            if (ls != main_stream) {
-                HIPCHK(h, hipEventRecord(h->ev_nw, main_stream));
+            if (ls != chain) {
+                HIPCHK(h, hipEventRecord(h->ev_nw, chain));
                 HIPCHK(h, hipStreamWaitEvent(ls, h->ev_nw, 0));
             }
             PROF(2, 0, ls)

@@ -300,8 +300,9 @@ int asm_accuracy_async(asm_handle* h, const int32_t* d_nw, const int32_t* d_leap
  * half of its time, the aligners are instruction-bound); this call's aligners wait for it.  With 2 the caller guarantees that
  * nothing it enqueued since the previous call on this batch changes what pack reads.
  * 3 = OVERLAPPED CALLS, the form a caller with a stream of batches (or of passes) wants: as 2, and in addition nothing of this
- * call waits for the previous call's Greedy kernel — consecutive calls form three chains (NW -> LEAP -> NW ..., Greedy -> Greedy,
- * pack -> pack) with each call's counters behind its own aligners on a fourth stream.  The caller's stream is NOT joined: the
+ * call waits for the previous call's Greedy kernel — consecutive calls form three chains on streams of the library (NW -> LEAP
+ * -> counters -> NW ..., Greedy -> Greedy, pack -> pack; a call's counters also wait for its Greedy).  The caller's stream is
+ * NOT joined: the
  * outputs and counters of all calls so far are complete on it after asm_pipeline_join_async (asm_synchronize also waits for
  * them).  The caller ALTERNATES between two sets of output arrays from call to call (a set is written again two calls later,
  * when the library has seen its counters finish), and calls asm_pipeline_join_async before it touches the batch or the outputs
