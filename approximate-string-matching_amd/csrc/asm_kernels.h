@@ -1532,23 +1532,32 @@ __global__ __launch_bounds__(ASM_BLOCK) void accuracy_kernel(const int32_t* __re
     const int4* leap4 = reinterpret_cast<const int4*>(leap);
     const int4* greedy4 = reinterpret_cast<const int4*>(greedy);
     const int4* ans4 = reinterpret_cast<const int4*>(answers);
-    for (long q = i; q < n4; q += stride) {
-        int4 p = make_int4(INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN);
-        if (nw != nullptr) p = nw4[q];
-        int4 want = p;
-        if (answers != nullptr) {
-            const int4 a = ans4[q];
-            want.x = a.x != INT32_MIN ? a.x : p.x, want.y = a.y != INT32_MIN ? a.y : p.y;
-            want.z = a.z != INT32_MIN ? a.z : p.z, want.w = a.w != INT32_MIN ? a.w : p.w;
+    // ... and ACC_AHEAD such groups in flight per thread: with one group per iteration the kernel is a chain of HBM round trips
+    // (eight of them at 10^6 pairs), which is what it costs inside a step, where it sits on the NW -> LEAP -> counters chain.
+    constexpr int ACC_AHEAD = 4;
+    for (long q0 = i; q0 < n4; q0 += ACC_AHEAD * stride) {
+        int4 p[ACC_AHEAD], a[ACC_AHEAD], l[ACC_AHEAD], g[ACC_AHEAD];
+#pragma unroll
+        for (int u = 0; u < ACC_AHEAD; u++) {
+            const long q = q0 + u * stride;
+            const long qq = q < n4 ? q : q0; /* a group beyond the end re-reads the first one and is not counted */
+            p[u] = a[u] = l[u] = g[u] = make_int4(INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN);
+            if (nw != nullptr) p[u] = nw4[qq];
+            if (answers != nullptr) a[u] = ans4[qq];
+            if (leap != nullptr) l[u] = leap4[qq];
+            if (greedy != nullptr) g[u] = greedy4[qq];
         }
-        if (nw != nullptr) c_nw += (p.x == want.x) + (p.y == want.y) + (p.z == want.z) + (p.w == want.w);
-        if (leap != nullptr) {
-            const int4 l = leap4[q];
-            c_leap += (l.x == want.x) + (l.y == want.y) + (l.z == want.z) + (l.w == want.w);
-        }
-        if (greedy != nullptr) {
-            const int4 g = greedy4[q];
-            c_greedy += (g.x == want.x) + (g.y == want.y) + (g.z == want.z) + (g.w == want.w);
+#pragma unroll
+        for (int u = 0; u < ACC_AHEAD; u++) {
+            if (q0 + u * stride >= n4) break;
+            int4 want = p[u];
+            if (answers != nullptr) {
+                want.x = a[u].x != INT32_MIN ? a[u].x : p[u].x, want.y = a[u].y != INT32_MIN ? a[u].y : p[u].y;
+                want.z = a[u].z != INT32_MIN ? a[u].z : p[u].z, want.w = a[u].w != INT32_MIN ? a[u].w : p[u].w;
+            }
+            if (nw != nullptr) c_nw += (p[u].x == want.x) + (p[u].y == want.y) + (p[u].z == want.z) + (p[u].w == want.w);
+            if (leap != nullptr) c_leap += (l[u].x == want.x) + (l[u].y == want.y) + (l[u].z == want.z) + (l[u].w == want.w);
+            if (greedy != nullptr) c_greedy += (g[u].x == want.x) + (g[u].y == want.y) + (g[u].z == want.z) + (g[u].w == want.w);
         }
     }
     for (long r = (n4 << 2) + i; r < n_cmp; r += stride) { /* the last n mod 4 pairs */
