@@ -44,7 +44,7 @@ def test_sequential_mode_matches_reference_order_dependence(asm, engine, oracle)
 
 @pytest.mark.parametrize("wl,n,k", [("C5", 12000, 3), ("C1", 10000, 3), ("C4", 8000, 2)])
 def test_sequential_mode_device_resolver(asm, engine, oracle, wl, n, k):
-    """The stale-tail chain is resolved on the GPU (csrc/asm_tails.h: three passes over 2560-pair chunks), both for
+    """The stale-tail chain is resolved on the GPU (csrc/asm_tails.h: three passes over 40-pair chunks), both for
     uploaded batches and for batches generated on the device; mixed lengths make long carry chains."""
     cfg, _, _ = asm.workload(wl)
     hb = asm.generate_pairs(cfg, 17, n)
@@ -61,9 +61,11 @@ def test_sequential_mode_ragged_lengths(asm, engine, oracle):
     _check("ragged-seq", got, want, hb)
 
 
-@pytest.mark.parametrize("sizes", [(7001, 5000, 2999), (2560, 2560, 10), (13, 0, 9000, 1), (25000,)])
+@pytest.mark.parametrize("sizes", [(7001, 5000, 2999), (2560, 2560, 10), (13, 0, 9000, 1), (25000,),
+                                   (5120, 40, 5121, 39, 1), (41, 5119, 10, 10247, 3)])
 def test_sequential_mode_chains_across_batches(asm, engine, oracle, sizes):
-    """One file cut into shards / chunks (sizes with every phase mod 10, an empty one, one spanning several 2560-pair chunks):
+    """One file cut into shards / chunks (sizes with every phase mod 10, an empty one, sizes at and around the resolver's
+    40-pair chunks and 5120-pair workgroups, one spanning several workgroups):
     summary per shard on the device -> fold on the host -> resolve each shard from the folded state.  Equals the reference as
     run over the WHOLE file (oracle mode 0, and the compiled reference where it travelled), which shards that each start from
     empty buffers do not."""
