@@ -2152,10 +2152,13 @@ int asm_stream_seq_file(asm_handle* h, const char* path, const asm_params* p, in
     hipEvent_t ev_shipped[3] = {nullptr, nullptr, nullptr}; /* the H2D copy out of host slot q is over */
     /* the reader side lives in asm_host.h (no HIP there: the same code runs under ThreadSanitizer in host/asm_host_check.cpp);
      * the one thing it needs from the device is "has the copy out of this slot finished" */
+    /* large chunks ramp up from a sixteenth (asm_host::SeqReader): the transfer of the first chunk starts after 1/16 of a chunk
+     * has been read instead of after a whole one */
+    const size_t first_chunk = chunk >= ((size_t)32 << 20) ? chunk / 16 : chunk;
     asm_host::SeqReader rd(fd, file_bytes, chunk, reader_threads, max_pairs, [&](int q) {
         (void)hipSetDevice(h->device);
         (void)hipEventSynchronize(ev_shipped[q]);
-    });
+    }, first_chunk);
     char* d_raw[2] = {nullptr, nullptr};
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
@@ -2264,10 +2267,12 @@ int asm_stream_seq_file(asm_handle* h, const char* path, const asm_params* p, in
         const size_t shipped = pend_bytes[q];
         if (n <= 0 || rc) return;
         harvest(q); /* the chunk two back used the same result staging */
-        if (n > pen_cap) { /* staging sized by the largest chunk so far (chunks hold about the same number of pairs); pen_cap = 0
-                              until the first chunk — not "is the NW buffer there", which a mask without NW never satisfies */
+        if (n > pen_cap) { /* staging sized from the first chunk for a full one (its pairs per byte, times the slot's bytes, plus an
+                              eighth: chunks ramp up to `chunk`); pen_cap = 0 until the first chunk — not "is the NW buffer there",
+                              which a mask without NW never satisfies */
             harvest(q ^ 1);
-            const int64_t cap = n + n / 8 + 1024;
+            const int64_t full = (int64_t)((double)n / (double)(shipped ? shipped : 1) * (double)slot_cap) + 1;
+            const int64_t cap = (full > n ? full : n) + (full > n ? full : n) / 8 + 1024;
             for (int qq = 0; qq < 2 && !rc; qq++)
                 for (int a = 0; a < 3 && !rc; a++) {
                     if (!((aligner_mask >> a) & 1)) continue;

@@ -312,7 +312,7 @@ struct SeqSlot { /* one (pinned) host buffer */
  * slot back (consumed), after which the reader may refill it once wait_shipped(slot) says the copy is over. */
 class SeqReader {
     const int fd_;
-    const size_t file_bytes_, chunk_;
+    const size_t file_bytes_, chunk_, first_chunk_;
     const int reader_threads_;
     const int64_t max_pairs_;
     const std::function<void(int)> wait_shipped_;
@@ -343,7 +343,10 @@ class SeqReader {
             size_t have = carry.size();
             if (have) memcpy(s.buf, carry.data(), have);
             carry.clear();
-            size_t want = chunk_;
+            /* chunk c takes first_chunk << c file bytes until that reaches `chunk`: the consumer's pipeline (ship, parse, align) starts
+             * after the FIRST chunk is in memory, so a small first chunk shortens the fill of the pipeline and the large later ones
+             * keep the per-chunk costs rare */
+            size_t want = c < 30 && (first_chunk_ << c) < chunk_ ? first_chunk_ << c : chunk_;
             if (file_off + want > file_bytes_) want = file_bytes_ - file_off;
             if (have + want > s.cap - 8) want = s.cap - 8 - have;
             NlScan sc = read_and_scan(workers, fd_, s.buf, have, want, (off_t)file_off, failed_);
@@ -388,9 +391,11 @@ class SeqReader {
 public:
     SeqSlot slot[3]; /* the caller sets buf and cap (usable bytes; allocate cap + 64) before start() */
 
-    SeqReader(int fd, size_t file_bytes, size_t chunk, int reader_threads, int64_t max_pairs, std::function<void(int)> wait_shipped)
-        : fd_(fd), file_bytes_(file_bytes), chunk_(chunk), reader_threads_(reader_threads), max_pairs_(max_pairs),
-          wait_shipped_(std::move(wait_shipped)) {}
+    /* first_chunk: file bytes of chunk 0 (0 or >= chunk: every chunk takes `chunk`) */
+    SeqReader(int fd, size_t file_bytes, size_t chunk, int reader_threads, int64_t max_pairs, std::function<void(int)> wait_shipped,
+              size_t first_chunk = 0)
+        : fd_(fd), file_bytes_(file_bytes), chunk_(chunk), first_chunk_(first_chunk > 0 && first_chunk < chunk ? first_chunk : chunk),
+          reader_threads_(reader_threads), max_pairs_(max_pairs), wait_shipped_(std::move(wait_shipped)) {}
     ~SeqReader() { stop(); }
     void start() { reader_ = std::thread([this] { loop(); }); }
     /* consumer: chunk c (in order, c = 0, 1, ...); nullptr when reading failed (or one pair is longer than a chunk) */

@@ -53,7 +53,7 @@ static std::string make_text(const asm_gen_config& cfg, int64_t first, int64_t n
 
 /* Streams `text` (written to `path`) through SeqReader; returns what the consumer received, concatenated. */
 static std::string stream_file(const std::string& path, const std::string& text, size_t chunk, int readers, int64_t max_pairs,
-                               int64_t* pairs_seen, int* chunks_seen, bool* failed, size_t slack = (size_t)4 << 10) {
+                               int64_t* pairs_seen, int* chunks_seen, bool* failed, size_t slack = (size_t)4 << 10, size_t first_chunk = 0) {
     FILE* f = fopen(path.c_str(), "wb");
     fwrite(text.data(), 1, text.size(), f);
     fclose(f);
@@ -63,7 +63,7 @@ static std::string stream_file(const std::string& path, const std::string& text,
     std::future<void> copy[3]; /* the "copy stream": an asynchronous reader of the slot's buffer */
     SeqReader rd(fd, text.size(), chunk, readers, max_pairs, [&](int q) {
         if (copy[q].valid()) copy[q].wait();
-    });
+    }, first_chunk);
     for (int q = 0; q < 3; q++) rd.slot[q].buf = bufs[(size_t)q].data(), rd.slot[q].cap = cap;
     rd.start();
     std::deque<std::string> parts; /* a deque: elements stay where they are while asynchronous copies write into them */
@@ -141,6 +141,18 @@ int main(int argc, char** argv) {
         EXPECT(pairs == want_pairs, "chunk %zu readers %d: %lld pairs, want %lld", c.chunk, c.readers, (long long)pairs, (long long)want_pairs);
         EXPECT(got == first_pairs(text, want_pairs), "chunk %zu readers %d: bytes differ (%zu against %zu)", c.chunk, c.readers, got.size(),
                first_pairs(text, want_pairs).size());
+    }
+    {   /* chunks that ramp up from a small first one: the same bytes, more chunks than the full size alone would give */
+        int64_t pairs = 0;
+        int chunks_flat = 0, chunks_ramp = 0;
+        bool failed = false;
+        std::string got = stream_file(path, text, 1 << 19, 3, 0, &pairs, &chunks_flat, &failed);
+        EXPECT(!failed && pairs == n && got == text, "flat 512 KB chunks");
+        got = stream_file(path, text, 1 << 19, 3, 0, &pairs, &chunks_ramp, &failed, (size_t)4 << 10, 1 << 15);
+        EXPECT(!failed && pairs == n && got == text, "ramped chunks: %lld pairs", (long long)pairs);
+        EXPECT(chunks_ramp > chunks_flat, "ramp: %d chunks against %d", chunks_ramp, chunks_flat);
+        got = stream_file(path, text, 1 << 19, 2, 4321, &pairs, &chunks_ramp, &failed, (size_t)4 << 10, 600); /* a first chunk of barely a pair */
+        EXPECT(!failed && pairs == 4321 && got == first_pairs(text, 4321), "ramp from 600 bytes: %lld pairs", (long long)pairs);
     }
     {   /* a last line without its newline; a file that ends on a read line (the reference gets an empty string there) */
         int64_t pairs = 0;
