@@ -342,6 +342,9 @@ static hipError_t launch_greedy(asm_handle* h, const asm_bucket& b, const Greedy
                              (long)b.n, b.w4, ga, out, cig, h->refill_greedy);
 }
 
+#define LEAP_UNIT_WIDE_K 5 /* thread-per-pair unit-cost LEAP at every string length up to this band */
+#define LEAP_UNIT_MAX_K 10 /* ... and for strings of one granule (<= 128 characters) up to this one (k = 12: 0.148 ms against
+                              0.180 at C2, but 0.120 against 0.104 at C4's 2.5 % errors, where four threads per pair have little to do) */
 template <int K, int W64>
 static hipError_t launch_leap_unit_w(asm_handle* h, const asm_bucket& b, OutMap out, const int32_t* hint) {
     if (hint && h->leap_hint) {
@@ -433,9 +436,12 @@ static hipError_t launch_leap_general(asm_handle* h, const asm_bucket& b, const 
 template <int K>
 static hipError_t launch_leap_unit(asm_handle* h, const asm_bucket& b, OutMap out, const int32_t* hint) {
     if (b.maxlen <= 128) return launch_leap_unit_w<K, 2>(h, b, out, hint);
-    if (b.maxlen <= 192) return launch_leap_unit_w<K, 3>(h, b, out, hint);
-    if (b.maxlen <= 256) return launch_leap_unit_w<K, 4>(h, b, out, hint);
-    return launch_leap_unit_w<K, 6>(h, b, out, hint);
+    if constexpr (K <= LEAP_UNIT_WIDE_K) { /* the wider bands (6..8 lanes each side) are kept in registers for one granule only */
+        if (b.maxlen <= 192) return launch_leap_unit_w<K, 3>(h, b, out, hint);
+        if (b.maxlen <= 256) return launch_leap_unit_w<K, 4>(h, b, out, hint);
+        return launch_leap_unit_w<K, 6>(h, b, out, hint);
+    }
+    return hipErrorInvalidValue; /* not reached: align_bucket sends such buckets to the four-threads-per-pair kernel */
 }
 
 static int ensure_todo(asm_handle* h, size_t n) {
@@ -1315,13 +1321,21 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
             /* LV's other ED_modes have no caller in the reference: one kernel serves them, the workgroup-per-pair form that takes
              * any band and any penalties (asm_wide.h) */
             launch_leap_wide(h->stream, planes, lens, b.n, b.w4, p->k, p->x, p->o, p->e, out, (int)p->leap_mode);
-        } else if (unit && p->k >= 1 && p->k <= 5 && b.maxlen <= 384) {
+        } else if (unit && p->k >= 1 && ((p->k <= LEAP_UNIT_WIDE_K && b.maxlen <= 384) || (p->k <= LEAP_UNIT_MAX_K && b.maxlen <= 128))) {
+            /* thread per pair, band lanes in registers: k <= 5 at any length; k = 6..10 for strings of one granule, where the
+             * four-threads-per-pair kernel is 1.6-2 x slower (C2, 10^6 pairs, k = 6 / 8 / 10: 0.085 / 0.089 / 0.111 ms against
+             * 0.174 / 0.181 / 0.180) */
             switch (p->k) {
                 case 1: HIPCHK(h, launch_leap_unit<1>(h, b, out, hint)); break;
                 case 2: HIPCHK(h, launch_leap_unit<2>(h, b, out, hint)); break;
                 case 3: HIPCHK(h, launch_leap_unit<3>(h, b, out, hint)); break;
                 case 4: HIPCHK(h, launch_leap_unit<4>(h, b, out, hint)); break;
-                default: HIPCHK(h, launch_leap_unit<5>(h, b, out, hint)); break;
+                case 5: HIPCHK(h, launch_leap_unit<5>(h, b, out, hint)); break;
+                case 6: HIPCHK(h, launch_leap_unit<6>(h, b, out, hint)); break;
+                case 7: HIPCHK(h, launch_leap_unit<7>(h, b, out, hint)); break;
+                case 8: HIPCHK(h, launch_leap_unit<8>(h, b, out, hint)); break;
+                case 9: HIPCHK(h, launch_leap_unit<9>(h, b, out, hint)); break;
+                default: HIPCHK(h, launch_leap_unit<10>(h, b, out, hint)); break;
             }
         } else if (!unit && p->k >= 1 && p->k <= 5 && b.maxlen <= 256 && h->wave_kernels &&
                    RingGeometry(p->x, p->o, p->e).lds_bytes(2 * p->k + 1, LEAP_GEN_THREADS) <= 64 * 1024) {

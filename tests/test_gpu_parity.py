@@ -123,8 +123,10 @@ def test_c5_mixed_lengths(asm, engine, oracle):
     _check("greedy", engine.align(batch, asm.GREEDY, params), oracle.greedy(hb, k=3, mode=1), hb)
 
 
-@pytest.mark.parametrize("k", [0, 1, 2, 4, 5, 6, 10, 50])
+@pytest.mark.parametrize("k", [0, 1, 2, 4, 5, 6, 7, 8, 9, 10, 11, 50])
 def test_band_widths(asm, engine, oracle, k):
+    """Every dispatch boundary of the band: LEAP thread per pair up to k = 10 for strings of one granule (5 beyond), four threads
+    per pair from there; Greedy thread per pair up to 16, then wave(s) per pair."""
     cfg, _, _ = asm.workload("C2")
     hb = asm.generate_pairs(cfg, 7, 3000)
     params = asm.Params.default(k=k)
