@@ -430,7 +430,8 @@ static int launch_nw_wfa(asm_handle* h, const asm_bucket& b, const asm_params* p
 template <int K>
 static hipError_t launch_leap_general(asm_handle* h, const asm_bucket& b, const asm_params* p, OutMap out) {
     if (b.maxlen <= 128) return launch_leap_general_w<K, 2>(h, b, p, out);
-    return launch_leap_general_w<K, 4>(h, b, p, out);
+    if constexpr (K <= 5) return launch_leap_general_w<K, 4>(h, b, p, out);
+    return hipErrorInvalidValue; /* not reached: bands 6..8 come here for strings of one granule only (align_bucket) */
 }
 
 template <int K>
@@ -1337,7 +1338,7 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
                 case 9: HIPCHK(h, launch_leap_unit<9>(h, b, out, hint)); break;
                 default: HIPCHK(h, launch_leap_unit<10>(h, b, out, hint)); break;
             }
-        } else if (!unit && p->k >= 1 && p->k <= 5 && b.maxlen <= 256 && h->wave_kernels &&
+        } else if (!unit && p->k >= 1 && ((p->k <= 5 && b.maxlen <= 256) || (p->k <= 8 && b.maxlen <= 128)) && h->wave_kernels &&
                    RingGeometry(p->x, p->o, p->e).lds_bytes(2 * p->k + 1, LEAP_GEN_THREADS) <= 64 * 1024) {
             /* general penalties, narrow band: thread per pair with an LDS generation ring */
             switch (p->k) {
@@ -1345,7 +1346,10 @@ static int align_bucket(asm_handle* h, const asm_bucket& b, int aligner, const a
                 case 2: HIPCHK(h, launch_leap_general<2>(h, b, p, out)); break;
                 case 3: HIPCHK(h, launch_leap_general<3>(h, b, p, out)); break;
                 case 4: HIPCHK(h, launch_leap_general<4>(h, b, p, out)); break;
-                default: HIPCHK(h, launch_leap_general<5>(h, b, p, out)); break;
+                case 5: HIPCHK(h, launch_leap_general<5>(h, b, p, out)); break;
+                case 6: HIPCHK(h, launch_leap_general<6>(h, b, p, out)); break;
+                case 7: HIPCHK(h, launch_leap_general<7>(h, b, p, out)); break;
+                default: HIPCHK(h, launch_leap_general<8>(h, b, p, out)); break;
             }
         } else if (h->wave_kernels && b.maxlen <= 512 &&
                    leap_quad_lds((b.maxlen + 31) / 32, (int)p->k, unit ? 2 : RingGeometry(p->x, p->o, p->e).gm,
