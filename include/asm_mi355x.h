@@ -212,7 +212,8 @@ int asm_align_batch(asm_handle* h, int aligner, int64_t n, const char* reads, co
  * asm_batch_from_text: a batch out of such a text held in host memory; the raw bytes go to the GPU as they are and are
  * parsed there (newline index, offsets, gather: csrc/asm_ingest.h). */
 int asm_batch_from_text(asm_handle* h, const char* text, size_t nbytes, int greedy_mode, asm_batch** out);
-/* asm_stream_seq_file: `read_string_file` + `run` for a file of any size, in chunks of about chunk_bytes (0 = 64 MiB): reader
+/* asm_stream_seq_file: `read_string_file` + `run` for a file of any size, in chunks of about chunk_bytes (0 = 64 MiB; from 32 MiB
+ * on, the first chunk is a sixteenth of that and the chunks double up to it, so that the first transfer starts early): reader
  * threads fill pinned buffers (three in rotation) and cut them at pair boundaries, the raw bytes are copied to HBM on a copy
  * stream while the chunk before is parsed, packed and aligned on the handle's stream, and results of the chunk before that are
  * handed over.  aligner_mask: bit 0 NW, 1 LEAP, 2 Greedy.  nw / leap / greedy: host arrays of out_cap entries (or NULL),
