@@ -440,6 +440,7 @@ static hipError_t launch_leap_unit(asm_handle* h, const asm_bucket& b, OutMap ou
     if constexpr (K <= LEAP_UNIT_WIDE_K) { /* the wider bands (6..8 lanes each side) are kept in registers for one granule only */
         if (b.maxlen <= 192) return launch_leap_unit_w<K, 3>(h, b, out, hint);
         if (b.maxlen <= 256) return launch_leap_unit_w<K, 4>(h, b, out, hint);
+        if (b.maxlen <= 320) return launch_leap_unit_w<K, 5>(h, b, out, hint); /* C5's longest class (257-300) on five words */
         return launch_leap_unit_w<K, 6>(h, b, out, hint);
     }
     return hipErrorInvalidValue; /* not reached: align_bucket sends such buckets to the four-threads-per-pair kernel */
